@@ -1,0 +1,161 @@
+"""Weight naming, deterministic synthetic weights and safetensors I/O.
+
+Key layout = what ``convert_to_hf.py`` saves for ``GARModel``
+(reference: hf_models/convert_to_hf.py:100-135; attribute names modeling_gar.py:48-60,
+modeling_perception_lm.py:179,223-224,438-441; leaf names are timm Eva / HF Llama):
+
+    mllm.model.vision_tower.timm_model.{patch_embed.proj.weight, cls_token, pos_embed, norm_pre.*,
+        blocks.{i}.{norm1,norm2}.{weight,bias}, blocks.{i}.attn.{qkv,proj}.{weight,bias},
+        blocks.{i}.{gamma_1,gamma_2}, blocks.{i}.mlp.{fc1,fc2}.{weight,bias}}
+    mllm.model.multi_modal_projector.linear_{1,2}.{weight,bias}
+    mllm.model.language_model.{embed_tokens.weight, layers.{i}.*, norm.weight}
+    mllm.lm_head.weight                       (absent/tied when tie_word_embeddings)
+    mask_patch_embedding.weight
+
+There are no released weights in this environment (no network); ``synthetic_weights`` draws every
+tensor from a per-name seeded CPU generator so any rank / process / test reproduces the same model.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+VT = "mllm.model.vision_tower.timm_model."
+PJ = "mllm.model.multi_modal_projector."
+LM = "mllm.model.language_model."
+
+
+def weight_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    v = cfg.mllm_config.vision_config
+    t = cfg.mllm_config.text_config
+    D, Dm, P = v.embed_dim, v.mlp_dim, v.patch_size
+    npt = 1 if cfg.mllm_config.vision_use_cls_token else 0
+    s: Dict[str, Tuple[int, ...]] = {}
+    s[VT + "patch_embed.proj.weight"] = (D, 3, P, P)
+    if npt:
+        s[VT + "cls_token"] = (1, 1, D)
+    s[VT + "pos_embed"] = (1, npt + v.num_patches, D)
+    s[VT + "norm_pre.weight"] = (D,)
+    s[VT + "norm_pre.bias"] = (D,)
+    for i in range(v.depth):
+        b = f"{VT}blocks.{i}."
+        s[b + "norm1.weight"] = (D,)
+        s[b + "norm1.bias"] = (D,)
+        s[b + "attn.qkv.weight"] = (3 * D, D)
+        s[b + "attn.qkv.bias"] = (3 * D,)
+        s[b + "attn.proj.weight"] = (D, D)
+        s[b + "attn.proj.bias"] = (D,)
+        s[b + "gamma_1"] = (D,)
+        s[b + "norm2.weight"] = (D,)
+        s[b + "norm2.bias"] = (D,)
+        s[b + "mlp.fc1.weight"] = (Dm, D)
+        s[b + "mlp.fc1.bias"] = (Dm,)
+        s[b + "mlp.fc2.weight"] = (D, Dm)
+        s[b + "mlp.fc2.bias"] = (D,)
+        s[b + "gamma_2"] = (D,)
+    C = t.hidden_size
+    s[PJ + "linear_1.weight"] = (C, D)
+    s[PJ + "linear_1.bias"] = (C,)
+    s[PJ + "linear_2.weight"] = (C, C)
+    s[PJ + "linear_2.bias"] = (C,)
+    s[LM + "embed_tokens.weight"] = (t.vocab_size, C)
+    for i in range(t.num_hidden_layers):
+        b = f"{LM}layers.{i}."
+        s[b + "input_layernorm.weight"] = (C,)
+        s[b + "self_attn.q_proj.weight"] = (t.num_attention_heads * t.head_dim, C)
+        s[b + "self_attn.k_proj.weight"] = (t.num_key_value_heads * t.head_dim, C)
+        s[b + "self_attn.v_proj.weight"] = (t.num_key_value_heads * t.head_dim, C)
+        s[b + "self_attn.o_proj.weight"] = (C, t.num_attention_heads * t.head_dim)
+        s[b + "post_attention_layernorm.weight"] = (C,)
+        s[b + "mlp.gate_proj.weight"] = (t.intermediate_size, C)
+        s[b + "mlp.up_proj.weight"] = (t.intermediate_size, C)
+        s[b + "mlp.down_proj.weight"] = (C, t.intermediate_size)
+    s[LM + "norm.weight"] = (C,)
+    if not t.tie_word_embeddings:
+        s["mllm.lm_head.weight"] = (t.vocab_size, C)
+    s["mask_patch_embedding.weight"] = (v.num_features, 3, P, P)
+    return s
+
+
+def _seed(name: str, seed: int) -> int:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return int.from_bytes(h[:8], "little") & 0x7FFFFFFFFFFFFFFF
+
+
+def _draw(name: str, shape, seed: int) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(_seed(name, seed))
+    return torch.empty(shape, dtype=torch.float32).normal_(0.0, 1.0, generator=g)
+
+
+def synthetic_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
+    """fp32 CPU tensor. Scales keep activations O(1) through the stack so fp32/bf16 error
+    analysis and greedy argmax margins are meaningful."""
+    leaf = name.rsplit(".", 1)[-1]
+    if name.endswith("norm.weight") or name.endswith("layernorm.weight") or \
+            ".norm1.weight" in name or ".norm2.weight" in name or name.endswith("norm_pre.weight"):
+        return 1.0 + 0.05 * _draw(name, shape, seed)
+    if leaf == "bias":
+        return 0.02 * _draw(name, shape, seed)
+    if leaf in ("gamma_1", "gamma_2"):
+        return 0.1 + 0.01 * _draw(name, shape, seed)       # LayerScale init_values=0.1
+    if leaf == "cls_token":
+        return 0.5 * _draw(name, shape, seed)
+    if leaf == "pos_embed":
+        return 0.2 * _draw(name, shape, seed)
+    if name.endswith("embed_tokens.weight"):
+        return 0.05 * _draw(name, shape, seed)
+    if name == "mllm.lm_head.weight":
+        return _draw(name, shape, seed) / math.sqrt(shape[1])
+    if name == "mask_patch_embedding.weight":
+        # zero-initialised in training (grasp_any_region.py:78-87); non-zero here so the mask path
+        # measurably changes the output
+        return 0.05 * _draw(name, shape, seed)
+    if "patch_embed.proj.weight" in name:
+        fan_in = shape[1] * shape[2] * shape[3]
+        return _draw(name, shape, seed) / math.sqrt(fan_in)
+    if len(shape) == 2:                                    # Linear [out, in]
+        return _draw(name, shape, seed) / math.sqrt(shape[1])
+    return 0.02 * _draw(name, shape, seed)
+
+
+def synthetic_weights(cfg, seed: int = 0, names: Iterable[str] = None) -> Dict[str, torch.Tensor]:
+    shapes = weight_shapes(cfg)
+    if names is None:
+        names = shapes.keys()
+    return {n: synthetic_tensor(n, shapes[n], seed) for n in names}
+
+
+def save_weights(weights: Dict[str, torch.Tensor], path: str) -> None:
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in weights.items()}, path)
+
+
+def load_weights(path: str) -> Dict[str, torch.Tensor]:
+    """Reads one ``.safetensors`` file or every shard in a HF checkpoint directory."""
+    import glob
+    import os
+    from safetensors import safe_open
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors"))) if os.path.isdir(path) else [path]
+    if not files:
+        raise FileNotFoundError(f"no .safetensors under {path}")
+    out = {}
+    for f in files:
+        with safe_open(f, framework="pt", device="cpu") as sf:
+            for k in sf.keys():
+                out[k] = sf.get_tensor(k)
+    return out
+
+
+def check_weights(cfg, weights: Dict[str, torch.Tensor]) -> None:
+    """Loud failure on a key/shape mismatch (the loader contract of SURVEY.md §8f.1)."""
+    shapes = weight_shapes(cfg)
+    missing = [k for k in shapes if k not in weights]
+    if missing:
+        raise KeyError(f"missing {len(missing)} weights, e.g. {missing[:4]}")
+    for k, shp in shapes.items():
+        if tuple(weights[k].shape) != tuple(shp):
+            raise ValueError(f"{k}: expected {shp}, got {tuple(weights[k].shape)}")

@@ -1,0 +1,125 @@
+"""CPU: host-side logic (processor, sample builders, config, weights) against outputs of the reference's own
+pure-Python helpers executed in the build container (tests/golden/ref_helpers.json, tools/make_goldens.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from gar_amd import GARConfig
+from gar_amd.eval_dataset import MultiRegionDataset, SingleRegionCaptionDataset
+from gar_amd.processing import GARProcessor, StubTokenizer, select_canvas, split_tiles
+from gar_amd.weights import check_weights, load_weights, save_weights, synthetic_weights, weight_shapes
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "ref_helpers.json")))
+
+
+def test_canvas_table_matches_reference(ref):
+    for w, h, mt, cw, ch in ref["canvas_table"]:
+        assert select_canvas(w, h, 448, mt) == (cw, ch), (w, h, mt)
+
+
+def test_split_matches_reference(ref):
+    r = ref["split_merge"]
+    ncw, nch, th, tw, C = r["ncw"], r["nch"], r["th"], r["tw"], r["C"]
+    img = torch.arange(C * nch * th * ncw * tw, dtype=torch.float32).view(1, C, nch * th, ncw * tw)
+    assert split_tiles(img, ncw, nch).flatten().tolist() == r["tiles"]
+
+
+def test_single_region_parse_matches_reference(ref, golden_dir):
+    d1 = ref["demo1"]
+    img = Image.new("RGBA", tuple(d1["size"]))
+    mask = np.array(Image.open(os.path.join(golden_dir, "demo_mask_1.png")).convert("L")).astype(bool)
+    proc = GARProcessor(StubTokenizer(), max_num_tiles=16)
+    ds = SingleRegionCaptionDataset(img, mask, proc, data_dtype=torch.float32, device="cpu")
+    d = ds._parse_annotations()
+    assert d["visual_prompt"].mode == d1["vp_mode"]
+    vals, cnts = np.unique(np.array(d["visual_prompt"]), return_counts=True)
+    assert {str(int(v)): int(c) for v, c in zip(vals, cnts)} == d1["hist"]
+    assert sorted(int(v) for v in np.unique(np.array(d["visual_prompt"].convert("RGB")))) == d1["rgb_uniques"]
+    assert {k: [float(x) for x in v] for k, v in d["bboxes"].items()} == d1["bboxes"]
+
+
+def test_multi_region_parse_matches_reference_including_quirks(ref, golden_dir):
+    d3 = ref["demo3"]
+    img = Image.new("RGB", tuple(d3["size"]))
+    masks = [np.array(Image.open(os.path.join(golden_dir, f"demo_mask_3_{i}.png")).convert("L")).astype(bool)
+             for i in range(3)]
+    proc = GARProcessor(StubTokenizer(), max_num_tiles=16)
+    ds = MultiRegionDataset(img, masks, d3["question"], proc, data_dtype=torch.float32, device="cpu",
+                            prompt_order=d3["order"])
+    d = ds._parse_annotations()
+    assert d["prompt"] == d3["prompt"]
+    vals, cnts = np.unique(np.array(d["visual_prompt"]), return_counts=True)
+    assert {str(int(v)): int(c) for v, c in zip(vals, cnts)} == d3["hist"]
+    got = {k: [float(x) for x in v] for k, v in d["bboxes"].items()}
+    assert got == d3["bboxes"]
+    assert len({tuple(v) for v in got.values()}) == 1          # stale mask_id quirk: all boxes = last mask's
+
+
+def test_sample_contract_full_size():
+    """Key names / shapes / dtypes of the generate kwargs (evaluation/eval_dataset.py:141-148) at 1024^2, mt16."""
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    cfg = GARConfig.gar_1b()
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16)
+    s = SingleRegionCaptionDataset(synthetic_image(0), synthetic_mask(0), proc, data_dtype=torch.bfloat16,
+                                   device="cpu")[0]
+    assert s["pixel_values"].shape == (17, 3, 448, 448) and s["pixel_values"].dtype == torch.bfloat16
+    assert s["global_mask_values"].shape == (17, 3, 448, 448)
+    assert s["aspect_ratios"].tolist() == [[4, 4]]
+    ids = s["input_ids"]
+    assert ids.dtype == torch.int64 and ids.shape[0] == 1
+    assert int((ids == 128002).sum()) == 17 * 256 and int((ids == 128005).sum()) == 256
+    assert s["attention_mask"].dtype == torch.bfloat16 and s["attention_mask"].shape == ids.shape
+    assert list(s["bboxes"][0].keys()) == ["128005"]
+    # mask values decode back to {prompt id 1, NO_Prompt 5} exactly, in bf16
+    mv = torch.round((s["global_mask_values"] + 1.0) / 2.0 * 255.0).long()
+    assert sorted(mv.unique().tolist()) == [1, 5]
+
+
+def test_tokenizer_roundtrip_and_special_ids():
+    tk = StubTokenizer()
+    assert tk.convert_tokens_to_ids("<|reserved_special_token_3|>") == 128005
+    assert [tk.convert_tokens_to_ids(f"<|reserved_special_token_{k + 2}|>") for k in range(5)] == \
+        GARConfig.gar_1b().crop_tokens_ids
+    assert tk.convert_tokens_to_ids("<NO_Prompt>") - 128256 == 5
+    text = "<|begin_of_text|>héllo <Prompt1>: <|image|>x"
+    ids = tk.encode(text)
+    assert tk.decode(ids) == text and tk.decode(ids, skip_special_tokens=True) == "héllo : x"
+
+
+def test_config_contract():
+    c = GARConfig.gar_1b()
+    assert c.prompt_numbers == 5 and c.kernel_size == [14, 14] and c.mask_path_embedding_out_channels == 1024
+    assert c.pooled_side == 16 and c.tokens_per_tile == 256 and c.feat_stride == 28
+    c8 = GARConfig.gar_8b()
+    assert c8.mask_path_embedding_out_channels == 1536 and not c8.mllm_config.vision_use_cls_token
+    assert c8.mllm_config.text_config.head_dim == 128 and c8.mllm_config.vision_config.mlp_dim == 8960
+    rt = GARConfig.from_dict(json.loads(json.dumps(c.to_dict())))
+    assert rt.to_dict() == c.to_dict()
+    with pytest.raises(AssertionError):
+        GARConfig(prompt_numbers=4)
+
+
+def test_weights_naming_and_io(tmp_path):
+    cfg = GARConfig.tiny()
+    W = synthetic_weights(cfg)
+    assert "mllm.lm_head.weight" not in W                       # tied
+    assert W["mllm.model.vision_tower.timm_model.pos_embed"].shape == (1, 65, 128)
+    p = str(tmp_path / "w.safetensors")
+    save_weights(W, p)
+    W2 = load_weights(p)
+    check_weights(cfg, W2)
+    assert all(torch.equal(W[k], W2[k]) for k in W)
+    W3 = synthetic_weights(cfg)
+    assert all(torch.equal(W[k], W3[k]) for k in W)             # deterministic per name
+    del W2["mask_patch_embedding.weight"]
+    with pytest.raises(KeyError):
+        check_weights(cfg, W2)
+    n1b = sum(int(np.prod(s)) for s in weight_shapes(GARConfig.gar_1b()).values())
+    assert 1.5e9 < n1b < 1.6e9

@@ -1,0 +1,158 @@
+"""CPU: the oracle (oracle/gar_oracle.py) against golden vectors captured from the third-party packages the
+reference calls (tools/make_goldens.py) and against known-answer tests."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+
+LM = "mllm.model.language_model."
+
+
+def _tcfg(**kw):
+    d = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+             num_key_value_heads=2, head_dim=64, vocab_size=512, rms_norm_eps=1e-5, rope_theta=500000.0,
+             rope_scaling={"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                           "original_max_position_embeddings": 8192, "rope_type": "llama3"},
+             tie_word_embeddings=True)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_llama_against_transformers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    W = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("W:")}
+    t = _tcfg()
+    emb = torch.from_numpy(g["inputs_embeds"])
+    assert np.allclose(O.llama_inv_freq(t).numpy(), g["inv_freq"], rtol=1e-6, atol=0)
+    for impl in ("eager", "sdpa"):
+        h = O.llama_forward(emb, W, t, O.KVCache(t.num_hidden_layers), impl)
+        logits = torch.nn.functional.linear(h, O.lm_head_weight(W, t))
+        ref = torch.from_numpy(g["logits"])
+        assert float((logits - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5
+        seq = O.greedy_generate(emb, W, t, max_new_tokens=12, attn_impl=impl)
+        assert seq.tolist() == g["sequences"].tolist()
+
+
+def test_llama3_inv_freq_real_dims(golden_dir):
+    g = np.load(os.path.join(golden_dir, "llama_inv_freq.npz"))
+    a = O.llama_inv_freq(_tcfg(head_dim=64))
+    assert np.allclose(a.numpy(), g["inv_freq_1b"], rtol=1e-6, atol=0)
+    sc = dict(_tcfg().rope_scaling, factor=8.0)
+    b = O.llama_inv_freq(_tcfg(head_dim=128, rope_scaling=sc))
+    assert np.allclose(b.numpy(), g["inv_freq_8b"], rtol=1e-6, atol=0)
+
+
+def test_projector_against_transformers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "projector_tiny.npz"))
+    W = {O.PJ + "linear_1.weight": torch.from_numpy(g["w1"]), O.PJ + "linear_1.bias": torch.from_numpy(g["b1"]),
+         O.PJ + "linear_2.weight": torch.from_numpy(g["w2"]), O.PJ + "linear_2.bias": torch.from_numpy(g["b2"])}
+    y = O.projector_forward(torch.from_numpy(g["x"]), W, 2)
+    assert y.shape == g["y"].shape
+    assert np.allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+
+
+def test_pool_is_exact_2x2_mean():
+    x = torch.randn(2, 64, 8)
+    W = {O.PJ + "linear_1.weight": torch.eye(8), O.PJ + "linear_1.bias": torch.zeros(8),
+         O.PJ + "linear_2.weight": torch.eye(8), O.PJ + "linear_2.bias": torch.zeros(8)}
+    y = O.projector_forward(x, W, 2)
+    g = torch.nn.functional.gelu(x).view(2, 8, 8, 8)
+    m = (g[:, 0::2, 0::2] + g[:, 0::2, 1::2] + g[:, 1::2, 0::2] + g[:, 1::2, 1::2]) / 4
+    assert torch.allclose(y, m.reshape(2, 16, 8), atol=1e-6)
+
+
+def test_vit_building_blocks_against_torch_modules(golden_dir):
+    g = np.load(os.path.join(golden_dir, "torch_ops.npz"))
+    y = torch.nn.functional.conv2d(torch.from_numpy(g["x"]), torch.from_numpy(g["conv_w"]), None, stride=14)
+    assert np.allclose(y.numpy(), g["conv_y"], atol=1e-5)
+    q, k, v = (torch.from_numpy(g[n]) for n in "qkv")
+    s = torch.softmax((q @ k.transpose(-1, -2)) * (16 ** -0.5), -1) @ v
+    assert np.allclose(s.numpy(), g["sdpa"], atol=1e-5)
+
+
+def test_merge_matches_reference_index_map(golden_dir):
+    r = json.load(open(os.path.join(golden_dir, "ref_helpers.json")))["split_merge"]
+    ncw, nch, th, tw, C = r["ncw"], r["nch"], r["th"], r["tw"], r["C"]
+    tiles = torch.tensor(r["tiles"]).view(1, ncw * nch, C, th, tw)
+    merged = O.merge_tiles(tiles, ncw, nch)
+    img = torch.arange(C * nch * th * ncw * tw, dtype=torch.float32).view(1, C, nch * th, ncw * tw)
+    assert r["roundtrip_equal"] and torch.equal(merged, img)
+
+
+# ---- RoI-align known answers ----------------------------------------------------------------
+def test_roi_align_constant_map():
+    f = torch.full((1, 5, 12, 9), 3.25)
+    out = O.roi_align(f, torch.tensor([[0, 1.3, 2.1, 7.7, 10.2]]), (4, 4), 0.5, 2, True)
+    assert torch.allclose(out, torch.full_like(out, 3.25))
+
+
+def test_roi_align_linear_ramp_is_sample_mean():
+    H, Wd = 16, 16
+    xs = torch.arange(Wd, dtype=torch.float32).view(1, 1, 1, Wd).expand(1, 1, H, Wd).contiguous()
+    roi = torch.tensor([[0, 2.0, 3.0, 10.0, 11.0]])
+    out = O.roi_align(xs, roi, (4, 4), 1.0, 2, True)
+    sw, bw = 2.0 - 0.5, 8.0 / 4
+    for pw in range(4):
+        exp = np.mean([sw + pw * bw + (ix + .5) * bw / 2 for ix in range(2)])
+        assert abs(float(out[0, 0, 1, pw]) - exp) < 1e-5
+
+
+def test_roi_align_out_of_range_samples_are_zero():
+    f = torch.ones(1, 1, 4, 4)
+    out = O.roi_align(f, torch.tensor([[0, -40.0, -40.0, -20.0, -20.0]]), (2, 2), 1.0, 2, True)
+    assert float(out.abs().max()) == 0.0
+
+
+def test_replay_demo1_known_answer():
+    """Demo-1 bbox with canvas (4,4): the double-scaled RoI lands in cells x,y in {1,2} of tile 0, so every replay
+    token is a convex blend of pooled tokens 17,18,33,34 of the first tile."""
+    from gar_amd import GARConfig
+    cfg = GARConfig.gar_1b()
+    bbox = (0.720703125, 0.8688311688311688, 0.7939453125, 0.9233766233766234)
+    roi, ss = O.replay_roi(bbox, 64, 64, cfg.feat_stride)
+    assert abs(ss - 1 / 28) < 1e-15
+    sw = roi[1] * ss - 0.5
+    assert abs(sw - 1.1473) < 1e-3 and abs(roi[3] * ss - 0.5 - 1.3147) < 1e-3
+    assert abs(roi[2] * ss - 0.5 - 1.4859) < 1e-3 and abs(roi[4] * ss - 0.5 - 1.6106) < 1e-3
+    C = 3
+    feats = torch.zeros(17, 256, C)
+    feats[1, 17, 0] = feats[1, 18, 0] = feats[1, 33, 0] = feats[1, 34, 0] = 1.0   # tile index 1 = first real tile
+    feats[1, :, 1] = 7.0
+    ids = torch.tensor([[1] * 4 + [128005] * 256 + [2] * 3])
+    emb = torch.zeros(1, ids.shape[1], C)
+    out = O.feature_replay(emb, ids, feats, torch.tensor([[4, 4]]), [{"128005": bbox}], cfg)
+    rep = out[0, 4:260]
+    assert torch.allclose(rep[:, 0], torch.ones(256), atol=1e-6)     # weights of the 4 cells sum to 1
+    assert torch.allclose(rep[:, 1], torch.full((256,), 7.0), atol=1e-5)
+    assert float(out[0, :4].abs().max()) == 0 and float(out[0, 260:].abs().max()) == 0
+
+
+def test_mask_decode_roundtrip_all_dtypes():
+    ids = torch.arange(0, 16, dtype=torch.float32)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        m = (ids / 255.0 - 0.5) / 0.5
+        b = O.decode_mask_values(m.to(dt), 5)
+        assert b.tolist() == [1.0] * 5 + [0.0] + [1.0] * 0 + [0.0] * 10 or b.tolist() == [float(i != 5 and i < 5) for i in range(16)]
+
+
+def test_end_to_end_tiny_runs_and_is_deterministic():
+    from gar_amd import GARConfig
+    from gar_amd.eval_dataset import SingleRegionCaptionDataset
+    from gar_amd.processing import GARProcessor
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.tiny()
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+    s = SingleRegionCaptionDataset(synthetic_image(0, 200, 160), synthetic_mask(0, 200, 160), proc,
+                                   data_dtype=torch.float32, device="cpu")[0]
+    a = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], s["aspect_ratios"], s["bboxes"],
+                       s["input_ids"], s["attention_mask"], max_new_tokens=6)
+    b = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], s["aspect_ratios"], s["bboxes"],
+                       s["input_ids"], s["attention_mask"], max_new_tokens=6, attn_impl="sdpa")
+    assert a.shape == (1, 6) and a.tolist() == b.tolist()
