@@ -1,0 +1,221 @@
+// Llama-side data movement kernels:
+//   llm_qkv_post   half-split RoPE (llama3-scaled tables) + q scale + head-major relayout + KV-cache append
+//                  (K [B,Hkv,Smax,hd], V transposed [B,Hkv,hd,Smax] so both attention kernels read 16-B MFMA fragments)
+//   embed_lookup   embedding rows of the just-sampled tokens
+//   argmax         greedy sampling with first-index tie break; writes into the device-side token matrix
+#include "common.h"
+
+// block = (batch b, 64-position chunk); loops over all heads of q, k, v.
+// thread (token nl = tid/ (HD/16), i8 = 8-wide slice of the FIRST half): rotates (x[i], x[i+HD/2]) pairs.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__ qkv, const float* __restrict__ cs,
+                                                           const float* __restrict__ sn, T* __restrict__ Q,
+                                                           T* __restrict__ Kc, T* __restrict__ Vtc, int S, int Spad,
+                                                           int Hq, int Hkv, int Smax, int pos0,
+                                                           const int32_t* __restrict__ pos_dev, float q_scale) {
+    constexpr int HALF = HD / 2;
+    constexpr int LPT = HALF / 8;               // lanes per token (4 for hd 64, 8 for hd 128)
+    constexpr int TPP = 256 / LPT;              // tokens per pass (64 / 32)
+    __shared__ T vs[64 * (HD + 2)];
+    const int chunks = (Spad + 63) / 64;
+    const int ch = blockIdx.x % chunks;
+    const int b = blockIdx.x / chunks;
+    const int tid = threadIdx.x;
+    const int i8 = (tid % LPT) * 8;
+    const int p0 = pos_dev ? pos_dev[0] : pos0;
+    const int W = (Hq + 2 * Hkv) * HD;
+    for (int head = 0; head < Hq + 2 * Hkv; ++head) {
+        const bool isq = head < Hq, isk = !isq && head < Hq + Hkv;
+        for (int pass = 0; pass < 64 / TPP; ++pass) {
+            const int nl = pass * TPP + tid / LPT;
+            const int s = ch * 64 + nl;
+            float x1[8], x2[8];
+            if (s < S) {
+                const T* row = qkv + ((int64_t)b * S + s) * W + head * HD;
+                ld8(row + i8, x1);
+                ld8(row + HALF + i8, x2);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x1[e] = x2[e] = 0.f;
+            }
+            if (isq || isk) {
+                if (s < S) {
+                    const float* cp = cs + (int64_t)(p0 + s) * HALF + i8;
+                    const float* sp = sn + (int64_t)(p0 + s) * HALF + i8;
+                    const float sc = isq ? q_scale : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {   // q*cos + rotate_half(q)*sin
+                        const float c = cp[e], sv = sp[e];
+                        const float o1 = x1[e] * c + (-x2[e]) * sv;
+                        const float o2 = x2[e] * c + x1[e] * sv;
+                        x1[e] = o1 * sc;
+                        x2[e] = o2 * sc;
+                    }
+                }
+                if (isq && s < Spad) {
+                    T* o = Q + (((int64_t)b * Hq + head) * Spad + s) * HD;
+                    st8(o + i8, x1);
+                    st8(o + HALF + i8, x2);
+                } else if (isk && s < S) {
+                    T* o = Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0 + s) * HD;
+                    st8(o + i8, x1);
+                    st8(o + HALF + i8, x2);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    DT<T>::st(&vs[nl * (HD + 2) + i8 + e], x1[e]);
+                    DT<T>::st(&vs[nl * (HD + 2) + HALF + i8 + e], x2[e]);
+                }
+            }
+        }
+        if (!isq && !isk) {
+            __syncthreads();
+            const int hv = head - Hq - Hkv;
+            T* vbase = Vtc + ((int64_t)b * Hkv + hv) * HD * (int64_t)Smax;
+            const int col0 = p0 + ch * 64;
+            const int nvalid = min(64, S - ch * 64);
+            if ((col0 & 7) == 0 && nvalid == 64) {
+                for (int d = tid / 8; d < HD; d += 32) {
+                    const int n8 = (tid % 8) * 8;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = DT<T>::ld(&vs[(n8 + e) * (HD + 2) + d]);
+                    st8(vbase + (int64_t)d * Smax + col0 + n8, o);
+                }
+            } else {                                   // ragged / unaligned (decode appends a single column)
+                for (int i = tid; i < HD * nvalid; i += 256) {
+                    const int d = i / nvalid, n = i % nvalid;
+                    vbase[(int64_t)d * Smax + col0 + n] = vs[n * (HD + 2) + d];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, const float* sn, void* Q, void* Kc,
+                                void* Vtc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
+                                const int32_t* pos_dev, float q_scale, gar_stream_t stream) {
+    GAR_CHECK_ARG(qkv && cs && sn && Q && Kc && Vtc, "llm_qkv_post: null pointer");
+    GAR_CHECK_ARG(B > 0 && S > 0 && Spad >= S && Smax % 64 == 0, "llm_qkv_post: bad shape");
+    GAR_CHECK_ARG(pos_dev || pos0 + S <= Smax, "llm_qkv_post: cache overflow %d+%d > %d", pos0, S, Smax);
+    GAR_CHECK_ARG(hd == 64 || hd == 128, "llm_qkv_post: head_dim %d not built (64, 128)", hd);
+    dim3 grid(B * ((Spad + 63) / 64)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_LQP(TT, HD_)                                                                                         \
+    hipLaunchKernelGGL((llm_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc,  \
+                       (TT*)Vtc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, q_scale)
+    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQP(bf16_t, 64); else LAUNCH_LQP(bf16_t, 128); }
+    else { if (hd == 64) LAUNCH_LQP(float, 64); else LAUNCH_LQP(float, 128); }
+#undef LAUNCH_LQP
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_lookup_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ E,
+                                                           T* __restrict__ out, int C, int64_t vocab) {
+    int64_t id = tokens[blockIdx.x];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const T* src = E + id * C;
+    T* dst = out + (int64_t)blockIdx.x * C;
+    for (int i = threadIdx.x * 8; i < C; i += 256 * 8) {
+        float v[8];
+        ld8(src + i, v);
+        st8(dst + i, v);
+    }
+}
+
+extern "C" int gar_embed_lookup(int dtype, const int64_t* tokens, const void* E, void* out, int B, int C, int64_t vocab,
+                                gar_stream_t stream) {
+    GAR_CHECK_ARG(tokens && E && out && B > 0 && C % 8 == 0, "embed_lookup: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((embed_lookup_kernel<bf16_t>), dim3(B), dim3(256), 0, s, tokens, (const bf16_t*)E, (bf16_t*)out,
+                           C, vocab);
+    else
+        hipLaunchKernelGGL((embed_lookup_kernel<float>), dim3(B), dim3(256), 0, s, tokens, (const float*)E, (float*)out, C,
+                           vocab);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// argmax: stage 1 = AM_BLOCKS partial (max, first index) per row; stage 2 = one wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+#define AM_BLOCKS 64
+
+__device__ __forceinline__ void am_better(float& bv, int& bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict__ logits, int64_t ld, int V,
+                                                             float* __restrict__ pv, int* __restrict__ pi) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const T* row = logits + (int64_t)b * ld;
+    const int per = (V + AM_BLOCKS - 1) / AM_BLOCKS;
+    const int lo = blk * per, hi = min(V, lo + per);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) am_better(bv, bi, DT<T>::ld(row + i), i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        am_better(bv, bi, ov, oi);
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) am_better(bv, bi, sv[w], si[w]);
+        pv[b * AM_BLOCKS + blk] = bv;
+        pi[b * AM_BLOCKS + blk] = bi;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                          int64_t* __restrict__ out_tokens, int64_t out_stride,
+                                                          const int32_t* __restrict__ step_dev,
+                                                          int64_t* __restrict__ cur_tokens) {
+    const int b = blockIdx.x;
+    float bv = pv[b * AM_BLOCKS + threadIdx.x];
+    int bi = pi[b * AM_BLOCKS + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        am_better(bv, bi, ov, oi);
+    }
+    if (threadIdx.x == 0) {
+        const int step = step_dev ? step_dev[0] : 0;
+        if (out_tokens) out_tokens[(int64_t)b * out_stride + step] = bi;
+        if (cur_tokens) cur_tokens[b] = bi;
+    }
+}
+
+extern "C" int64_t gar_argmax_workspace(int B, int V) {
+    (void)V;
+    return (int64_t)B * AM_BLOCKS * 8;
+}
+
+extern "C" int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens,
+                          int64_t out_stride, const int32_t* step_dev, int64_t* cur_tokens, void* workspace,
+                          gar_stream_t stream) {
+    GAR_CHECK_ARG(logits && workspace && B > 0 && V > 0 && (out_tokens || cur_tokens), "argmax: bad args");
+    float* pv = (float*)workspace;
+    int* pi = (int*)(pv + (int64_t)B * AM_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(AM_BLOCKS, B);
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((argmax_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, V, pv, pi);
+    else
+        hipLaunchKernelGGL((argmax_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, V, pv, pi);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, s, pv, pi, out_tokens, out_stride, step_dev, cur_tokens);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}

@@ -1,0 +1,216 @@
+// RoI-aligned feature replay and the sequence assembly around it (compiled with -ffp-contract=off: the RoI
+// arithmetic follows torchvision's roi_align CPU kernel op for op in fp32, no fused multiply-add).
+//
+//   placeholder_scan  image-token ranks + crop-token spans, device-side (replaces the .item()/numel() host syncs of
+//                     modeling_gar.py:356-360 and modeling_perception_lm.py:299-315)
+//   embed_assemble    nn.Embedding gather + masked_scatter in one pass
+//   roi_replay        _merge + .float() + roi_align + permute/flatten/cast + torch.cat splice as ONE kernel that
+//                     reads <= 4 corner cells per sample straight from the tile-major pooled features and writes
+//                     the P*P replay rows in place. One block per output token, lanes over channels (16-B vectors).
+//                     Algorithmic bytes per crop token: P*P*C*sizeof(T) written + <= 16 cells * C * sizeof(T) read.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void placeholder_scan_kernel(const int64_t* __restrict__ ids, int S,
+                                                                int64_t image_id, const int64_t* __restrict__ crop_ids,
+                                                                int n_crop, int32_t* __restrict__ slot,
+                                                                int32_t* __restrict__ counts,
+                                                                int32_t* __restrict__ spans) {
+    __shared__ int wave_tot[16];
+    __shared__ int smin[8], smax[8];
+    __shared__ int running;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* row = ids + (int64_t)b * S;
+    if (tid < 8) { smin[tid] = 0x7fffffff; smax[tid] = -1; }
+    if (tid == 0) running = 0;
+    int64_t cid[8];
+    for (int c = 0; c < 8; ++c) cid[c] = c < n_crop ? crop_ids[c] : (int64_t)-0x7fffffffffffLL;
+    int lmin[8], lmax[8];
+    for (int c = 0; c < 8; ++c) { lmin[c] = 0x7fffffff; lmax[c] = -1; }
+    __syncthreads();
+    for (int base = 0; base < S; base += 1024) {
+        const int s = base + tid;
+        const int64_t v = s < S ? row[s] : (int64_t)-1;
+        const bool flag = s < S && v == image_id;
+        const unsigned long long m = __ballot(flag);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (s < S) {
+            slot[(int64_t)b * S + s] = flag ? off + prefix : -1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (v == cid[c]) { lmin[c] = min(lmin[c], s); lmax[c] = max(lmax[c], s); }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+            running += tot;
+        }
+        __syncthreads();
+    }
+    for (int c = 0; c < n_crop; ++c) {
+        if (lmax[c] >= 0) { atomicMin(&smin[c], lmin[c]); atomicMax(&smax[c], lmax[c]); }
+    }
+    __syncthreads();
+    if (tid == 0) counts[b] = running;
+    if (tid < n_crop) {
+        spans[((int64_t)b * n_crop + tid) * 2 + 0] = smax[tid] >= 0 ? smin[tid] : -1;
+        spans[((int64_t)b * n_crop + tid) * 2 + 1] = smax[tid];
+    }
+}
+
+extern "C" int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int64_t image_token_id,
+                                    const int64_t* crop_ids, int n_crop, int32_t* slot, int32_t* counts, int32_t* spans,
+                                    gar_stream_t stream) {
+    GAR_CHECK_ARG(input_ids && slot && counts && spans && B > 0 && S > 0, "placeholder_scan: bad args");
+    GAR_CHECK_ARG(n_crop >= 0 && n_crop <= 8 && (n_crop == 0 || crop_ids), "placeholder_scan: n_crop must be <= 8");
+    hipLaunchKernelGGL(placeholder_scan_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, input_ids, S,
+                       image_token_id, crop_ids, n_crop, slot, counts, spans);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_assemble_kernel(const int64_t* __restrict__ ids,
+                                                             const int32_t* __restrict__ slot, const T* __restrict__ E,
+                                                             const T* __restrict__ feats, T* __restrict__ out, int S,
+                                                             int C, int64_t n_feat_rows, int64_t vocab) {
+    const int64_t r = blockIdx.x;                         // row over B*S
+    const int b = (int)(r / S);
+    const int32_t sl = slot ? slot[r] : -1;
+    const T* src;
+    if (sl >= 0) {
+        src = feats + ((int64_t)b * n_feat_rows + min((int64_t)sl, n_feat_rows - 1)) * C;
+    } else {
+        int64_t id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = E + id * C;
+    }
+    T* dst = out + r * C;
+    for (int i = threadIdx.x * 8; i < C; i += 256 * 8) {
+        if (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+        else {
+            reinterpret_cast<float4*>(dst + i)[0] = reinterpret_cast<const float4*>(src + i)[0];
+            reinterpret_cast<float4*>(dst + i)[1] = reinterpret_cast<const float4*>(src + i)[1];
+        }
+    }
+}
+
+extern "C" int gar_embed_assemble(int dtype, const int64_t* input_ids, const int32_t* slot, const void* E,
+                                  const void* feats, void* out, int B, int S, int C, int64_t n_feat_rows, int64_t vocab,
+                                  gar_stream_t stream) {
+    GAR_CHECK_ARG(input_ids && E && out && B > 0 && S > 0 && C % 8 == 0, "embed_assemble: bad args");
+    GAR_CHECK_ARG(!slot || (feats && n_feat_rows > 0), "embed_assemble: slot without feats");
+    dim3 grid((unsigned)((int64_t)B * S)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((embed_assemble_kernel<bf16_t>), grid, block, 0, s, input_ids, slot, (const bf16_t*)E,
+                           (const bf16_t*)feats, (bf16_t*)out, S, C, n_feat_rows, vocab);
+    else
+        hipLaunchKernelGGL((embed_assemble_kernel<float>), grid, block, 0, s, input_ids, slot, (const float*)E,
+                           (const float*)feats, (float*)out, S, C, n_feat_rows, vocab);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// roi_replay
+// ---------------------------------------------------------------------------------------------------------------
+struct Sample { int yl, yh, xl, xh; float w1, w2, w3, w4; bool valid; };
+
+// torchvision pre_calc_for_bilinear_interpolate, fp32
+__device__ __forceinline__ Sample make_sample(float y, float x, int H, int W) {
+    Sample s;
+    s.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+    const float ly = y - (float)yl, lx = x - (float)xl;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    s.yl = yl; s.yh = yh; s.xl = xl; s.xh = xh;
+    s.w1 = hy * hx; s.w2 = hy * lx; s.w3 = ly * hx; s.w4 = ly * lx;
+    if (!s.valid) { s.yl = s.yh = s.xl = s.xh = 0; s.w1 = s.w2 = s.w3 = s.w4 = 0.f; }
+    return s;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void roi_replay_kernel(const T* __restrict__ feats, T* __restrict__ embeds,
+                                                         const int32_t* __restrict__ spans, int crop_index,
+                                                         int first_tile, int ncw, int nch, int P, int C, int S,
+                                                         float rx1, float ry1, float rx2, float ry2, float ss,
+                                                         int aligned) {
+    const int head = spans[2 * crop_index];
+    if (head < 0) return;                                   // crop token absent from input_ids
+    const int bin = blockIdx.x;
+    const int ph = bin / P, pw = bin % P;
+    const int row = head + bin;
+    if (row >= S) return;
+    const int H = nch * P, W = ncw * P;
+    const float off = aligned ? 0.5f : 0.0f;
+    const float sw = rx1 * ss - off, sh = ry1 * ss - off, ew = rx2 * ss - off, eh = ry2 * ss - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const float count = (float)(G * G);
+    Sample smp[G * G];
+#pragma unroll
+    for (int iy = 0; iy < G; ++iy) {
+        const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)G;
+#pragma unroll
+        for (int ix = 0; ix < G; ++ix) {
+            const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)G;
+            smp[iy * G + ix] = make_sample(y, x, H, W);
+        }
+    }
+    auto cell = [&](int y, int x) -> const T* {            // merged-map cell (y,x) in the tile-major layout
+        const int tile = first_tile + (y / P) * ncw + (x / P);
+        return feats + ((int64_t)tile * P * P + (y % P) * P + (x % P)) * C;
+    };
+    T* dst = embeds + (int64_t)row * C;
+    for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < G * G; ++k) {
+            const Sample& s = smp[k];
+            float v1[8], v2[8], v3[8], v4[8];
+            ld8(cell(s.yl, s.xl) + c, v1);
+            ld8(cell(s.yl, s.xh) + c, v2);
+            ld8(cell(s.yh, s.xl) + c, v3);
+            ld8(cell(s.yh, s.xh) + c, v4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[e] = acc[e] + (((s.w1 * v1[e] + s.w2 * v2[e]) + s.w3 * v3[e]) + s.w4 * v4[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] / count;
+        st8(dst + c, acc);
+    }
+}
+
+extern "C" int gar_roi_replay(int dtype, const void* feats, void* embeds, const int32_t* spans, int crop_index,
+                              int first_tile, int ncw, int nch, int P, int C, int S, float rx1, float ry1, float rx2,
+                              float ry2, float spatial_scale, int sampling_ratio, int aligned, gar_stream_t stream) {
+    GAR_CHECK_ARG(feats && embeds && spans, "roi_replay: null pointer");
+    GAR_CHECK_ARG(ncw > 0 && nch > 0 && P > 0 && C % 8 == 0 && S > 0 && crop_index >= 0, "roi_replay: bad shape");
+    GAR_CHECK_ARG(sampling_ratio == 2, "roi_replay: sampling_ratio %d not built (the reference uses 2)", sampling_ratio);
+    dim3 grid(P * P), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((roi_replay_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)feats, (bf16_t*)embeds, spans,
+                           crop_index, first_tile, ncw, nch, P, C, S, rx1, ry1, rx2, ry2, spatial_scale, aligned);
+    else
+        hipLaunchKernelGGL((roi_replay_kernel<float, 2>), grid, block, 0, s, (const float*)feats, (float*)embeds, spans,
+                           crop_index, first_tile, ncw, nch, P, C, S, rx1, ry1, rx2, ry2, spatial_scale, aligned);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}

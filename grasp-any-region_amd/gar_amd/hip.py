@@ -1,0 +1,109 @@
+"""ctypes binding of libgar_hip.so (include/gar_hip.h). There is NO fallback: a missing library, a missing symbol,
+an ABI mismatch or a non-gfx950 device raises. torch is used only to hold device memory and the stream."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgar_hip.so")
+
+GAR_F32, GAR_BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS = range(7)
+ABI_VERSION = 1
+
+
+class GarError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("epilogue", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("gamma", C.c_void_p), ("pos", C.c_void_p), ("tokens_in", C.c_int32), ("tokens_out", C.c_int32),
+                ("token_offset", C.c_int32), ("reserved", C.c_int32)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "gar_abi_version": ([], _i),
+    "gar_last_error": ([], C.c_char_p),
+    "gar_check_device": ([_i], _i),
+    "gar_gemm": ([_i, C.POINTER(GemmParams), _vp], _i),
+    "gar_patch_im2col": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "gar_cls_pos_fill": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "gar_layernorm": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
+    "gar_rmsnorm": ([_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
+    "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp], _i),
+    "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "gar_pool2x2": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp], _i),
+    "gar_embed_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp], _i),
+    "gar_roi_replay": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _vp], _i),
+    "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
+    "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "gar_argmax_workspace": ([_i, _i], _i64),
+    "gar_counter_add": ([_vp, _i, _i, _vp], _i),
+}
+
+_lib = None
+
+
+def load_library(path: str = None):
+    """Loads the shared library and binds every symbol of include/gar_hip.h; raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise GarError(f"{path} not found — build it with `python __graft_entry__.py` or "
+                       f"`make -C grasp-any-region_amd/csrc` (there is no CPU/PyTorch fallback)")
+    lib = C.CDLL(path)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GarError(f"{path} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    v = lib.gar_abi_version()
+    if v != ABI_VERSION:
+        raise GarError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load_library()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().gar_last_error()
+        raise GarError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def require_device(device_index: int = 0):
+    if not torch.cuda.is_available():
+        raise GarError("no GPU visible: gar_amd has no CPU path (the oracle under oracle/ is test infrastructure only)")
+    check(lib().gar_check_device(device_index), "gar_check_device")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return GAR_F32
+    if dt == torch.bfloat16:
+        return GAR_BF16
+    raise GarError(f"unsupported dtype {dt} (float32 parity mode or bfloat16)")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

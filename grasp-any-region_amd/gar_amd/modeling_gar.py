@@ -1,0 +1,484 @@
+"""GARModel — host-side sequencing of the region-captioning hot path on one MI355X.
+
+Keeps the call surface of the reference's ``GARModel`` (projects/grasp_any_region/hf_models/modeling_gar.py):
+``model.config.prompt_numbers``, ``model.generate(input_ids=, attention_mask=, pixel_values=, global_mask_values=,
+bboxes=, aspect_ratios=, generation_config=, return_dict=)`` -> object with ``.sequences`` (new tokens only, :418-426),
+``get_image_features`` (modeling_perception_lm.py:239-269).  Everything numeric is a HIP kernel behind the C ABI
+(``gar_amd.ops``); this file only allocates buffers, orders launches and captures the decode step in a hipGraph.
+
+Differences by design: the mask conv + patch-embed conv are one im2col GEMM; ``_merge`` and the fp32
+copy of the feature map are never materialised (``gar_roi_replay`` indexes the tile layout); placeholder / crop-token
+bookkeeping runs on the device, so ``generate`` has no host sync before the first EOS check.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import hip, ops
+from .configuration_gar import GARConfig
+from .weights import LM, PJ, VT, check_weights, load_weights, synthetic_weights
+
+LOG2E = 1.4426950408889634
+
+
+@dataclass
+class GenerateOutput:
+    sequences: torch.Tensor                      # [B, n_new] int64 (only new tokens, as with inputs_embeds in HF)
+    logits: Optional[torch.Tensor] = None        # [B, n_new, V] when return_logits=True (tests)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _rope2d_tables(v) -> (torch.Tensor, torch.Tensor):
+    """timm RotaryEmbeddingCat tables: host-side constant generation, fp32."""
+    hd, g, nb = v.head_dim, v.grid, v.head_dim // 4
+    bands = 1.0 / (v.rope_temperature ** (torch.arange(0, nb, dtype=torch.int64).to(torch.float32) / nb))
+    t = torch.arange(g, dtype=torch.int64).to(torch.float32) + v.rope_grid_offset
+    g0, g1 = torch.meshgrid(t, t, indexing=v.rope_grid_indexing)
+    pos = torch.stack([g0, g1], dim=-1).unsqueeze(-1) * bands
+    sin = pos.sin().reshape(g * g, -1).repeat_interleave(2, -1)
+    cos = pos.cos().reshape(g * g, -1).repeat_interleave(2, -1)
+    return sin.contiguous(), cos.contiguous()
+
+
+def _llama_inv_freq(t) -> torch.Tensor:
+    """HF rope init incl. rope_type 'llama3' (SURVEY.md A.4): host-side constant generation, fp32."""
+    dim = t.head_dim
+    inv = 1.0 / (t.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(torch.float32) / dim))
+    sc = t.rope_scaling
+    if sc and sc.get("rope_type", sc.get("type", "llama3")) == "llama3":
+        factor, low, high, old = sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"], \
+            sc["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv
+        inv_l = torch.where(wavelen > old / low, inv / factor, inv)
+        smooth = (old / wavelen - low) / (high - low)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        med = ~(wavelen < old / high) * ~(wavelen > old / low)
+        inv = torch.where(med, smoothed, inv_l)
+    return inv
+
+
+class GARModel:
+    def __init__(self, config: GARConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
+                 device: str = "cuda:0"):
+        self.device = torch.device(device)
+        hip.require_device(self.device.index or 0)
+        self.config = config
+        self.dtype = dtype
+        self.prompt_numbers = config.prompt_numbers
+        self.crop_tokens_ids = list(config.crop_tokens_ids)
+        check_weights(config, weights)
+        self._prepare_weights(weights)
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._graphs: Dict[tuple, object] = {}
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    @classmethod
+    def from_synthetic(cls, config: GARConfig, seed: int = 0, dtype=torch.bfloat16, device="cuda:0"):
+        return cls(config, synthetic_weights(config, seed), dtype, device)
+
+    @classmethod
+    def from_pretrained(cls, path: str, dtype=torch.bfloat16, device="cuda:0", config: GARConfig = None):
+        import os
+        if config is None:
+            config = GARConfig.from_json_file(os.path.join(path, "config.json"))
+        return cls(config, load_weights(path), dtype, device)
+
+    @classmethod
+    def from_shapes(cls, config: GARConfig, dtype=torch.bfloat16, device="cuda:0"):
+        """Replica with UNINITIALISED device weights of the right shapes — to be filled by ``broadcast_weights``
+        (non-source ranks of the data-parallel runner never touch host weights)."""
+        from .weights import weight_shapes
+        W = {k: torch.empty(s, dtype=dtype, device=device) for k, s in weight_shapes(config).items()}
+        return cls(config, W, dtype, device)
+
+    def weight_tensors(self) -> List[torch.Tensor]:
+        ts = [self.w_patch, self.pos, *self.norm_pre, *self.pj.values(), self.E, self.final_norm]
+        if self.cls is not None:
+            ts.append(self.cls)
+        if self.lm_head is not self.E:
+            ts.append(self.lm_head)
+        for blk in self.vblocks:
+            for v in blk.values():
+                ts.extend(v if isinstance(v, tuple) else [v])
+        for ly in self.layers:
+            ts.extend(ly.values())
+        return ts
+
+    def broadcast_weights(self, src: int = 0):
+        """RCCL broadcast of every prepared weight tensor from rank ``src`` (one-off, bucketed)."""
+        from .dp import broadcast_tensors
+        broadcast_tensors(self.weight_tensors(), src)
+
+    def eval(self):
+        return self
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _prepare_weights(self, W: Dict[str, torch.Tensor]):
+        cfg = self.config
+        v, t = cfg.mllm_config.vision_config, cfg.mllm_config.text_config
+        pp = v.patch_size * v.patch_size
+        self.Kp = _round_up(6 * pp, 64)
+        D = v.embed_dim
+        wcat = torch.zeros(D, self.Kp, dtype=torch.float32, device=W[VT + "patch_embed.proj.weight"].device)
+        wcat[:, :3 * pp] = W[VT + "patch_embed.proj.weight"].float().flatten(1)
+        wcat[:, 3 * pp:6 * pp] = W["mask_patch_embedding.weight"].float().flatten(1)
+        d = self._dev
+        self.w_patch = d(wcat)
+        self.npt = 1 if cfg.mllm_config.vision_use_cls_token else 0
+        self.cls = d(W[VT + "cls_token"].reshape(-1)) if self.npt else None
+        self.pos = d(W[VT + "pos_embed"].reshape(-1, D))
+        self.norm_pre = (d(W[VT + "norm_pre.weight"]), d(W[VT + "norm_pre.bias"]))
+        self.vblocks = []
+        for i in range(v.depth):
+            b = f"{VT}blocks.{i}."
+            self.vblocks.append(dict(
+                n1=(d(W[b + "norm1.weight"]), d(W[b + "norm1.bias"])),
+                qkv_w=d(W[b + "attn.qkv.weight"]), qkv_b=d(W[b + "attn.qkv.bias"]),
+                proj_w=d(W[b + "attn.proj.weight"]), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
+                n2=(d(W[b + "norm2.weight"]), d(W[b + "norm2.bias"])),
+                fc1_w=d(W[b + "mlp.fc1.weight"]), fc1_b=d(W[b + "mlp.fc1.bias"]),
+                fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"])))
+        self.pj = dict(w1=d(W[PJ + "linear_1.weight"]), b1=d(W[PJ + "linear_1.bias"]),
+                       w2=d(W[PJ + "linear_2.weight"]), b2=d(W[PJ + "linear_2.bias"]))
+        sin, cos = _rope2d_tables(v)
+        self.vit_sin, self.vit_cos = sin.to(self.device), cos.to(self.device)
+        self.E = d(W[LM + "embed_tokens.weight"])
+        self.lm_head = self.E if t.tie_word_embeddings or "mllm.lm_head.weight" not in W else d(W["mllm.lm_head.weight"])
+        self.layers = []
+        F = t.intermediate_size
+        assert F % 16 == 0
+        for i in range(t.num_hidden_layers):
+            b = f"{LM}layers.{i}."
+            qkv = torch.cat([W[b + "self_attn.q_proj.weight"], W[b + "self_attn.k_proj.weight"],
+                             W[b + "self_attn.v_proj.weight"]], dim=0)
+            g, u = W[b + "mlp.gate_proj.weight"], W[b + "mlp.up_proj.weight"]
+            # [gate16 | up16] row interleave expected by GAR_EPI_SWIGLU
+            gu = torch.stack([g.view(F // 16, 16, -1), u.view(F // 16, 16, -1)], dim=1).reshape(2 * F, -1)
+            self.layers.append(dict(ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv),
+                                    o=d(W[b + "self_attn.o_proj.weight"]),
+                                    ln2=d(W[b + "post_attention_layernorm.weight"]), gu=d(gu),
+                                    down=d(W[b + "mlp.down_proj.weight"])))
+        self.final_norm = d(W[LM + "norm.weight"])
+        self.inv_freq = _llama_inv_freq(t)
+        self.crop_ids_dev = torch.tensor(self.crop_tokens_ids, dtype=torch.int64, device=self.device)
+        self._rope_cache = {}
+
+    def _llm_rope(self, max_pos: int):
+        if max_pos not in self._rope_cache:
+            pos = torch.arange(max_pos, dtype=torch.float32)
+            fr = pos[:, None] * self.inv_freq[None, :]
+            self._rope_cache[max_pos] = (fr.cos().contiguous().to(self.device), fr.sin().contiguous().to(self.device))
+        return self._rope_cache[max_pos]
+
+    def _buf(self, key: tuple, name: str, shape, dtype=None, zero=False):
+        d = self._ws.setdefault(key, {})
+        t = d.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.dtype, device=self.device)
+            d[name] = t
+        return t
+
+    # ---- vision tower + projector (A1-A6) -----------------------------------------------------------------------------
+    def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None):
+        """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l]."""
+        cfg = self.config
+        v = cfg.mllm_config.vision_config
+        C_l = cfg.mllm_config.text_config.hidden_size
+        if pixel_values.dim() == 5:
+            pixel_values = pixel_values.flatten(0, 1)
+        assert pixel_values.dim() == 4, f"pixel_values should be [tiles, 3, H, W], got {tuple(pixel_values.shape)}"
+        pix = pixel_values.to(self.device, self.dtype).contiguous()
+        msk = None
+        if global_mask_values is not None:
+            msk = global_mask_values.to(self.device, self.dtype).reshape(pix.shape).contiguous()
+        Tt = pix.shape[0]
+        n, D, Dm, H, hd = v.num_patches, v.embed_dim, v.mlp_dim, v.num_heads, v.head_dim
+        N = n + self.npt
+        Npad = _round_up(N, 64)
+        key = ("vit", Tt)
+        A = self._buf(key, "im2col", (Tt * n, self.Kp))
+        x = self._buf(key, "x", (Tt, N, D))
+        hbuf = self._buf(key, "h", (Tt * N, D))
+        qkv = self._buf(key, "qkv", (Tt * N, 3 * D))
+        Q = self._buf(key, "Q", (Tt, H, Npad, hd))
+        K = self._buf(key, "K", (Tt, H, Npad, hd))
+        Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
+        att = self._buf(key, "att", (Tt * N, D))
+        f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
+        ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
+        x2 = x.view(Tt * N, D)
+        ops.gemm(A, self.w_patch, x2, hip.EPI_PATCH_POS, pos=self.pos, tokens_in=n, tokens_out=N, token_offset=self.npt)
+        if self.npt:
+            ops.cls_pos_fill(x, self.cls, self.pos)
+        ops.layernorm(x2, *self.norm_pre, v.ln_eps)
+        q_scale = (hd ** -0.5) * LOG2E
+        for blk in self.vblocks:
+            ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
+            ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
+            ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
+            ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
+            ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])
+            ops.layernorm(x2, *blk["n2"], v.ln_eps, out=hbuf)
+            f1v = f1.view(-1)[:Tt * N * Dm].view(Tt * N, Dm)
+            ops.gemm(hbuf, blk["fc1_w"], f1v, hip.EPI_BIAS_GELU, bias=blk["fc1_b"])
+            ops.gemm(f1v, blk["fc2_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["fc2_b"], residual=x2, gamma=blk["g2"])
+        # projector over all N tokens of a tile (cls row included, dropped by the pooling window)
+        p1 = f1.view(-1)[:Tt * N * C_l].view(Tt * N, C_l)
+        ops.gemm(x2, self.pj["w1"], p1, hip.EPI_BIAS_GELU, bias=self.pj["b1"])
+        p2 = self._buf(key, "p2", (Tt * N, C_l))
+        ops.gemm(p1, self.pj["w2"], p2, hip.EPI_BIAS, bias=self.pj["b2"])
+        P = cfg.pooled_side
+        feats = self._buf(key, "feats", (Tt, P * P, C_l))
+        if cfg.mllm_config.projector_pooling_ratio == 2:
+            ops.pool2x2(p2, feats, v.grid, in_tile_tokens=N, in_token_offset=self.npt)
+        else:
+            raise hip.GarError("projector_pooling_ratio != 2 is not built")
+        return feats
+
+    # ---- inputs_embeds: embedding + placeholder scatter + RoI replay (A7-A11) -----------------------------------------
+    def build_inputs_embeds(self, input_ids, feats, bboxes, aspect_ratios, tiles_per_sample: int, validate=True):
+        cfg = self.config
+        B, S = input_ids.shape
+        C_l = cfg.mllm_config.text_config.hidden_size
+        P = cfg.pooled_side
+        key = ("emb", B, S)
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        slot = self._buf(key, "slot", (B, S), torch.int32)
+        counts = self._buf(key, "counts", (B,), torch.int32)
+        spans = self._buf(key, "spans", (B, len(self.crop_tokens_ids), 2), torch.int32)
+        embeds = self._buf(key, "embeds", (B, S, C_l))
+        ops.placeholder_scan(ids, cfg.mllm_config.image_token_id, self.crop_ids_dev, slot, counts, spans)
+        n_rows = tiles_per_sample * P * P
+        ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
+        if validate:
+            # reference errors (modeling_perception_lm.py:309-315, modeling_gar.py:356-360) need the counts on the host
+            cnt = counts.tolist()
+            sp = spans.tolist()
+            for b in range(B):
+                if cnt[b] != n_rows:
+                    raise ValueError(f"Image features and image tokens do not match: tokens: {cnt[b]}, features {n_rows}")
+        ar = aspect_ratios.tolist() if torch.is_tensor(aspect_ratios) else aspect_ratios
+        for b in range(B):
+            ncw, nch = int(ar[b][0]), int(ar[b][1])
+            assert ncw * nch == tiles_per_sample - 1, f"{ncw * nch} != {tiles_per_sample - 1}"
+            feat_h, feat_w = P * nch, P * ncw
+            for ci, crop_token in enumerate(self.crop_tokens_ids):
+                if str(crop_token) not in bboxes[b]:
+                    if validate and sp[b][ci][1] >= 0:
+                        raise KeyError(str(crop_token))
+                    continue
+                if validate:
+                    if sp[b][ci][1] < 0:
+                        continue            # token not in input_ids: the reference skips it (:356)
+                    if sp[b][ci][1] - sp[b][ci][0] + 1 != P * P:
+                        raise ValueError(f"crop token {crop_token} spans {sp[b][ci]} but the replay is {P * P} rows")
+                # box math of modeling_gar.py:366-387 in Python floats, then fp32 like torch.tensor(..., float32)
+                x1, y1, x2, y2 = [float(z) for z in bboxes[b][str(crop_token)]]
+                orig_h, orig_w = feat_h * cfg.feat_stride, feat_w * cfg.feat_stride
+                ss = feat_w / orig_w
+                roi = (x1 * orig_w * ss, y1 * orig_h * ss, x2 * orig_w * ss, y2 * orig_h * ss)
+                ops.roi_replay(feats[b * tiles_per_sample:(b + 1) * tiles_per_sample], embeds[b], spans[b], ci, 1, ncw,
+                               nch, P, C_l, S, roi, ss, 2, True)
+        return embeds
+
+    # ---- Llama (A12) --------------------------------------------------------------------------------------------------
+    def _llm_state(self, B: int, Smax: int):
+        t = self.config.mllm_config.text_config
+        key = ("llm", B, Smax)
+        L, Hkv, hd = t.num_hidden_layers, t.num_key_value_heads, t.head_dim
+        st = dict(
+            Kc=self._buf(key, "Kc", (L, B, Hkv, Smax, hd), zero=True),
+            Vtc=self._buf(key, "Vtc", (L, B, Hkv, hd, Smax), zero=True),
+            counters=self._buf(key, "counters", (4,), torch.int32, zero=True),   # [pos, kv_len, step, -]
+            cur=self._buf(key, "cur", (B,), torch.int64, zero=True),
+        )
+        return key, st
+
+    def _prefill(self, embeds: torch.Tensor, st, Smax: int):
+        t = self.config.mllm_config.text_config
+        B, S, C_l = embeds.shape
+        Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
+        key = ("prefill", B, S)
+        h = embeds.view(B * S, C_l)
+        xn = self._buf(key, "xn", (B * S, C_l))
+        qkv = self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
+        Spad = _round_up(S, 64)
+        Q = self._buf(key, "Q", (B, Hq, Spad, hd))
+        att = self._buf(key, "att", (B * S, Hq * hd))
+        ff = self._buf(key, "ff", (B * S, F))
+        cos, sin = self._llm_rope(Smax)
+        q_scale = (hd ** -0.5) * LOG2E
+        for li, ly in enumerate(self.layers):
+            ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+            ops.gemm(xn, ly["qkv"], qkv)
+            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale)
+            ops.attention(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
+            ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
+            ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
+            ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+            ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
+        return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
+
+    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, logits_keep=None):
+        """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed)."""
+        t = self.config.mllm_config.text_config
+        C_l, V = t.hidden_size, t.vocab_size
+        key = ("head", B)
+        xn = self._buf(key, "xn", (B, C_l))
+        Vld = _round_up(V, 64)
+        logits = self._buf(key, "logits", (B, Vld))
+        ws = self._buf(key, "amws", (ops.argmax_workspace(B, V),), torch.uint8)
+        ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
+        ops.gemm(xn, self.lm_head, logits)
+        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], st["cur"], ws)
+        return logits
+
+    def _decode_step(self, st, B: int, Smax: int, out_tokens):
+        t = self.config.mllm_config.text_config
+        C_l = t.hidden_size
+        Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
+        key = ("decode", B)
+        h = self._buf(key, "h", (B, C_l))
+        xn = self._buf(key, "xn", (B, C_l))
+        qkv = self._buf(key, "qkv", (B, (Hq + 2 * Hkv) * hd))
+        Q = self._buf(key, "Q", (B, Hq, 1, hd))
+        att = self._buf(key, "att", (B, Hq * hd))
+        ff = self._buf(key, "ff", (B, F))
+        cos, sin = self._llm_rope(Smax)
+        q_scale = (hd ** -0.5) * LOG2E
+        pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
+        ops.embed_lookup(st["cur"], self.E, h)
+        for li, ly in enumerate(self.layers):
+            ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+            ops.gemm(xn, ly["qkv"], qkv)
+            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale)
+            ops.attention(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False,
+                          kv_len_dev=kvlen_dev)
+            ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
+            ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
+            ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+            ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
+        logits = self._head(h, B, out_tokens, st)
+        ops.counter_add(st["counters"][0:3], 1)
+        return logits
+
+    # ---- generate -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, pixel_values=None, global_mask_values=None, aspect_ratios=None, bboxes=None, input_ids=None,
+                 attention_mask=None, generation_config=None, output_hidden_states=None, return_dict=None,
+                 max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
+                 return_logits: bool = False, sync_every: int = 16, **generate_kwargs) -> GenerateOutput:
+        """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428).
+
+        B = input_ids.shape[0] samples are processed together (the reference handles B=1 per call; its loop over
+        ``batch_idx`` is kept). ``pixel_values`` / ``global_mask_values``: [B*(T+1), 3, H, W] (flattened tiles as the
+        reference's callers pass them) or [B, T+1, 3, H, W]."""
+        gc = generation_config
+        if gc is not None:
+            get = (lambda k, d=None: gc.get(k, d)) if isinstance(gc, dict) else (lambda k, d=None: getattr(gc, k, d))
+            if get("do_sample", False):
+                raise hip.GarError("only greedy decoding (do_sample=False) is implemented, as the reference's callers use")
+            max_new_tokens = max_new_tokens or get("max_new_tokens")
+            if eos_token_id is None:
+                eos_token_id = get("eos_token_id")
+            pad_token_id = get("pad_token_id")
+        else:
+            pad_token_id = None
+        max_new_tokens = int(max_new_tokens or 64)
+        cfg = self.config
+        B, S = input_ids.shape
+        if validate and attention_mask is not None and not bool((attention_mask != 0).all()):
+            raise hip.GarError("padded attention_mask is not supported (the reference's callers pass all ones)")
+        if pixel_values is not None:
+            tiles = pixel_values.shape[0] // B if pixel_values.dim() == 4 else pixel_values.shape[1]
+            feats = self.get_image_features(pixel_values, global_mask_values)
+            embeds = self.build_inputs_embeds(input_ids, feats, bboxes, aspect_ratios, tiles, validate)
+        else:
+            ids = input_ids.to(self.device, torch.int64).contiguous()
+            embeds = self._buf(("emb", B, S), "embeds", (B, S, cfg.mllm_config.text_config.hidden_size))
+            ops.embed_assemble(ids, None, self.E, None, embeds, 0)
+        Smax = _round_up(S + max_new_tokens, 64)
+        skey, st = self._llm_state(B, Smax)
+        out_tokens = self._buf(skey, "out_tokens", (B, max_new_tokens), torch.int64, zero=True)
+        st["counters"].zero_()
+        last = self._prefill(embeds, st, Smax)
+        all_logits = []
+        lg = self._head(last, B, out_tokens, st)
+        if return_logits:
+            all_logits.append(lg[:, :cfg.mllm_config.text_config.vocab_size].float().clone())
+        # counters after prefill: pos = S (position of the next token), kv_len = S+1 (incl. it), step = 1
+        st["counters"].copy_(torch.tensor([S, S + 1, 1, 0], dtype=torch.int32), non_blocking=False)
+        eos = set()
+        if eos_token_id is not None:
+            eos = set(int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]))
+        graph = None
+        if use_graph and not return_logits and max_new_tokens > 1:
+            graph = self._decode_graph(st, B, Smax, out_tokens, skey)
+        n_done = 1
+        finished_at = [None] * B
+        while n_done < max_new_tokens:
+            if graph is not None:
+                graph.replay()
+            else:
+                lg = self._decode_step(st, B, Smax, out_tokens)
+                if return_logits:
+                    all_logits.append(lg[:, :cfg.mllm_config.text_config.vocab_size].float().clone())
+            n_done += 1
+            if eos and (n_done % sync_every == 0 or n_done == max_new_tokens):
+                if self._all_finished(out_tokens, n_done, eos, finished_at):
+                    break
+        seq = out_tokens[:, :n_done].clone()
+        if eos:
+            self._all_finished(out_tokens, n_done, eos, finished_at)
+            host = seq.tolist()
+            cut = max((f if f is not None else n_done) for f in finished_at)
+            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
+            for b in range(B):
+                if finished_at[b] is not None:
+                    for j in range(finished_at[b], cut):
+                        host[b][j] = pad
+                host[b] = host[b][:cut]
+            seq = torch.tensor(host, dtype=torch.int64, device=self.device)
+        return GenerateOutput(sequences=seq, logits=torch.stack(all_logits, 1) if return_logits else None)
+
+    @staticmethod
+    def _all_finished(out_tokens, n_done, eos, finished_at) -> bool:
+        host = out_tokens[:, :n_done].tolist()
+        for b, row in enumerate(host):
+            if finished_at[b] is None:
+                for j, tok in enumerate(row):
+                    if tok in eos:
+                        finished_at[b] = j + 1
+                        break
+        return all(f is not None for f in finished_at)
+
+    def _decode_graph(self, st, B, Smax, out_tokens, skey):
+        gkey = (skey, out_tokens.data_ptr(), out_tokens.shape[1])
+        g = self._graphs.get(gkey)
+        if g is None:
+            saved = st["counters"].clone()
+            saved_cur = st["cur"].clone()
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                       # warm-up launch outside capture (lazy module load)
+                self._decode_step(st, B, Smax, out_tokens)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            st["counters"].copy_(saved)
+            st["cur"].copy_(saved_cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._decode_step(st, B, Smax, out_tokens)
+            st["counters"].copy_(saved)                      # capture does not execute; keep state explicit
+            st["cur"].copy_(saved_cur)
+            self._graphs[gkey] = g
+        return g

@@ -1,0 +1,162 @@
+"""Operator-level Python mirror of include/gar_hip.h: tensors in, raw pointers + shapes out. Nothing here computes;
+every function enqueues one HIP kernel (or a fixed pair) on the current torch stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE, EPI_PATCH_POS, EPI_RES, EPI_SWIGLU,
+                  GemmParams, check, dtype_code, lib, ptr, stream)
+
+
+KERNEL_TIMERS = None     # bench.py sets this to a list to time GEMM launches with HIP events
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise hip.GarError(f"{name}: tensor must live on the GPU")
+    if not t.is_contiguous():
+        raise hip.GarError(f"{name}: tensor must be contiguous")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, bias=None, residual=None,
+         gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0):
+    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views."""
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(-1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    p = GemmParams()
+    p.A, p.lda = ptr(a), a.stride(0)
+    p.W, p.ldw = ptr(w), w.stride(0)
+    p.C = ptr(out)
+    p.ldc = out.stride(-2) if out.dim() >= 2 else out.shape[-1]
+    p.M, p.N, p.K = M, N, K
+    p.epilogue = epilogue
+    p.bias = ptr(bias)
+    p.residual = ptr(residual)
+    p.ldr = residual.stride(-2) if residual is not None else 0
+    p.gamma = ptr(gamma)
+    p.pos = ptr(pos)
+    p.tokens_in, p.tokens_out, p.token_offset = tokens_in, tokens_out, token_offset
+    prof = KERNEL_TIMERS
+    if prof is not None and not torch.cuda.is_current_stream_capturing():
+        # HIP events on the launch stream around this one kernel (bench.py roofline; never inside graph capture)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
+        e1.record()
+        kind = ("gemm_skinny" if M <= 16 else "gemm_tile") + ("_bf16" if a.dtype == torch.bfloat16 else "_f32")
+        prof.append((kind, 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), e0, e1))
+        return out
+    check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
+    return out
+
+
+def patch_im2col(pixel: torch.Tensor, mask: Optional[torch.Tensor], out: torch.Tensor, patch: int, prompt_numbers: int):
+    _chk(pixel, "pixel")
+    T, c, img, _ = pixel.shape
+    assert c == 3 and (mask is None or mask.shape == pixel.shape)
+    check(lib().gar_patch_im2col(dtype_code(pixel.dtype), ptr(pixel), ptr(mask), ptr(out), T, img, patch, out.shape[-1],
+                                 prompt_numbers, stream()), "gar_patch_im2col")
+    return out
+
+
+def cls_pos_fill(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor):
+    T, tokens, D = x.shape
+    check(lib().gar_cls_pos_fill(dtype_code(x.dtype), ptr(x), ptr(cls), ptr(pos), T, tokens, D, stream()),
+          "gar_cls_pos_fill")
+
+
+def _rows(x):
+    """(M, D, row stride) of a 2-D row-strided view or a contiguous [..., D] tensor."""
+    D = x.shape[-1]
+    assert x.stride(-1) == 1
+    if x.dim() == 2:
+        return x.shape[0], D, x.stride(0)
+    assert x.is_contiguous()
+    return x.numel() // D, D, D
+
+
+def layernorm(x, w, b, eps: float, out=None):
+    out = x if out is None else out
+    M, D, ldx = _rows(x)
+    _, _, ldy = _rows(out)
+    check(lib().gar_layernorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), ptr(b), M, D, ldx, ldy, eps, stream()),
+          "gar_layernorm")
+    return out
+
+
+def rmsnorm(x, w, eps: float, out=None):
+    out = x if out is None else out
+    M, D, ldx = _rows(x)
+    _, _, ldy = _rows(out)
+    check(lib().gar_rmsnorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), M, D, ldx, ldy, eps, stream()),
+          "gar_rmsnorm")
+    return out
+
+
+def vit_qkv_post(qkv, sin, cos, Q, K, Vt, T, N, npt, H, hd, Npad, q_scale):
+    check(lib().gar_vit_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(sin), ptr(cos), ptr(Q), ptr(K), ptr(Vt), T, N, npt,
+                                 H, hd, Npad, q_scale, stream()), "gar_vit_qkv_post")
+
+
+def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale):
+    check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vtc), B, S,
+                                 Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), q_scale, stream()), "gar_llm_qkv_post")
+
+
+def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None):
+    check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+                              kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention")
+
+
+def pool2x2(x, y, g: int, in_tile_tokens: int = 0, in_token_offset: int = 0):
+    """x [T, in_tile_tokens, C] (tokens in_token_offset .. +g*g of each tile are the g x g grid) -> y [T, (g/2)^2, C]"""
+    T, Cc = y.shape[0], y.shape[-1]
+    check(lib().gar_pool2x2(dtype_code(x.dtype), ptr(x), ptr(y), T, g, Cc, in_tile_tokens, in_token_offset, stream()),
+          "gar_pool2x2")
+    return y
+
+
+def placeholder_scan(input_ids, image_token_id, crop_ids_dev, slot, counts, spans):
+    B, S = input_ids.shape
+    assert input_ids.dtype == torch.int64 and input_ids.is_contiguous()
+    check(lib().gar_placeholder_scan(ptr(input_ids), B, S, int(image_token_id), ptr(crop_ids_dev),
+                                     crop_ids_dev.numel(), ptr(slot), ptr(counts), ptr(spans), stream()),
+          "gar_placeholder_scan")
+
+
+def embed_assemble(input_ids, slot, E, feats, out, n_feat_rows):
+    B, S = input_ids.shape
+    check(lib().gar_embed_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(feats), ptr(out), B, S,
+                                   E.shape[1], int(n_feat_rows), E.shape[0], stream()), "gar_embed_assemble")
+
+
+def roi_replay(feats, embeds, spans, crop_index, first_tile, ncw, nch, P, Cc, S, roi, spatial_scale,
+               sampling_ratio=2, aligned=True):
+    check(lib().gar_roi_replay(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), crop_index, first_tile, ncw,
+                               nch, P, Cc, S, roi[0], roi[1], roi[2], roi[3], spatial_scale, sampling_ratio,
+                               int(aligned), stream()), "gar_roi_replay")
+
+
+def embed_lookup(tokens, E, out):
+    check(lib().gar_embed_lookup(dtype_code(E.dtype), ptr(tokens), ptr(E), ptr(out), tokens.numel(), E.shape[1],
+                                 E.shape[0], stream()), "gar_embed_lookup")
+
+
+def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace):
+    B = logits.shape[0]
+    check(lib().gar_argmax(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
+                           ptr(step_dev), ptr(cur_tokens), ptr(workspace), stream()), "gar_argmax")
+
+
+def argmax_workspace(B, V) -> int:
+    return int(lib().gar_argmax_workspace(B, V))
+
+
+def counter_add(counters, delta: int):
+    check(lib().gar_counter_add(ptr(counters), counters.numel(), delta, stream()), "gar_counter_add")

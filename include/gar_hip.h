@@ -1,0 +1,158 @@
+/*
+ * gar_hip.h — C ABI of libgar_hip.so: the MI355X (gfx950 / CDNA4) device side of the Grasp-Any-Region
+ * region-captioning hot path.
+ *
+ * The reference (Haochen-Wang409/Grasp-Any-Region) is pure Python; it has no FFI of its own. Each entry
+ * point below therefore replaces a *third-party GPU op call site* on the reference's hot path, cited as
+ * file:line under /root/reference (see INTEGRATION.md for the binding a maintainer adds on the reference side).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + explicit shapes; no torch types; no allocation inside; no global state
+ *     other than a thread-local last-error string.
+ *   - every function returns 0 (GAR_OK) or a negative error code and never throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises
+ *     (safe for hipGraph capture).
+ *   - `dtype` selects the storage type of activations/weights: GAR_F32 (parity mode, exact-f32 MFMA/VALU math)
+ *     or GAR_BF16 (performance mode, bf16 storage, fp32 accumulation). Index tensors are int64 or int32 as stated.
+ *   - matrices are row-major; nn.Linear weights keep the PyTorch [out_features, in_features] layout.
+ */
+#ifndef GAR_HIP_H
+#define GAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAR_OK 0
+#define GAR_ERR_ARG (-1)
+#define GAR_ERR_LAUNCH (-2)
+#define GAR_ERR_ARCH (-3)
+#define GAR_ERR_UNSUPPORTED (-4)
+
+#define GAR_F32 0
+#define GAR_BF16 1
+
+#define GAR_ABI_VERSION 1
+
+/* GEMM epilogues */
+#define GAR_EPI_NONE 0            /* C = A W^T                                               */
+#define GAR_EPI_BIAS 1            /* C = A W^T + bias                                        */
+#define GAR_EPI_BIAS_GELU 2       /* C = gelu_erf(A W^T + bias)                              */
+#define GAR_EPI_BIAS_SCALE_RES 3  /* C = residual + gamma * (A W^T + bias)   (LayerScale)    */
+#define GAR_EPI_RES 4             /* C = residual + A W^T                                    */
+#define GAR_EPI_SWIGLU 5          /* W rows interleaved in blocks of 16: [gate16|up16]...;   */
+                                  /* C[:, N/2] = silu(gate) * up                             */
+#define GAR_EPI_PATCH_POS 6       /* row m -> tile m/tin, token tok_off + m%tin of a          */
+                                  /* [tiles, tout, N] output; C = A W^T + pos[tok_off+m%tin] */
+
+typedef void* gar_stream_t;
+
+int gar_abi_version(void);
+const char* gar_last_error(void);
+/* 0 if `device` is a gfx950 part, GAR_ERR_ARCH otherwise (the library holds gfx950 code objects only). */
+int gar_check_device(int device);
+
+typedef struct gar_gemm_params {
+    const void* A;  int64_t lda;       /* [M, K]                                                   */
+    const void* W;  int64_t ldw;       /* [N, K]  (nn.Linear weight)                               */
+    void* C;        int64_t ldc;       /* [M, N]  ([M, N/2] for SWIGLU)                            */
+    int32_t M, N, K;                   /* K % 64 == 0 (bf16) / K % 16 == 0 (f32); N % 16 == 0      */
+    int32_t epilogue;                  /* GAR_EPI_*                                                */
+    const void* bias;                  /* [N] or NULL                                              */
+    const void* residual; int64_t ldr; /* [M, N]                                                   */
+    const void* gamma;                 /* [N]                                                      */
+    const void* pos;                   /* PATCH_POS: [tokens_out, N]                               */
+    int32_t tokens_in, tokens_out, token_offset;
+    int32_t reserved;
+} gar_gemm_params;
+
+/* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
+ * modeling_perception_lm.py:210-214), projector linear_1/2 (modeling_perception_lm.py:85-92), Llama
+ * q/k/v/o/gate/up/down + lm_head (modeling_gar.py:418-426 -> HF LlamaModel), and the two 14x14/stride-14
+ * convolutions as one im2col GEMM (modeling_gar.py:326-328, modeling_perception_lm.py:194-196). */
+int gar_gemm(int dtype, const gar_gemm_params* p, gar_stream_t stream);
+
+/* A1+A2+K2 input side: mask decode round((m+1)/2*255)->clamp[0,P]->(v!=P) (modeling_gar.py:315-327) and patch
+ * extraction of both `pixel_values` and the binary mask into one GEMM operand:
+ *   out[T*g*g, Kp]: cols [0,3pp) = pixel patch in (c,ky,kx) order, [3pp,6pp) = binary mask patch, rest 0.
+ * `mask` may be NULL (then the mask columns are 0). */
+int gar_patch_im2col(int dtype, const void* pixel, const void* mask, void* out, int T, int img, int patch,
+                     int Kp, int prompt_numbers, gar_stream_t stream);
+
+/* cls token row: x[t, 0, :] = cls + pos[0]   (timm Eva._pos_embed, via modeling_perception_lm.py:197) */
+int gar_cls_pos_fill(int dtype, void* x, const void* cls, const void* pos, int T, int tokens, int D,
+                     gar_stream_t stream);
+
+/* nn.LayerNorm (norm_pre / norm1 / norm2 of the PE ViT) and HF LlamaRMSNorm. y may alias x.
+ * ldx / ldy = row strides in elements (<= 0 means D). */
+int gar_layernorm(int dtype, const void* x, void* y, const void* w, const void* b, int M, int D, int64_t ldx,
+                  int64_t ldy, float eps, gar_stream_t stream);
+int gar_rmsnorm(int dtype, const void* x, void* y, const void* w, int M, int D, int64_t ldx, int64_t ldy, float eps,
+                gar_stream_t stream);
+
+/* timm AttentionRope pre-attention step on the fused qkv output [T*N, 3*H*hd]: interleaved-pair 2-D RoPE on q,k
+ * for tokens >= npt (tables sin/cos [N-npt, hd] f32), softmax scale*log2(e) folded into q, and re-layout to
+ *   Q [T,H,Npad,hd], K [T,H,Npad,hd], Vt [T,H,hd,Npad]   (Vt pad columns zeroed). */
+int gar_vit_qkv_post(int dtype, const void* qkv, const float* sin, const float* cos, void* Q, void* K, void* Vt,
+                     int T, int N, int npt, int H, int hd, int Npad, float q_scale, gar_stream_t stream);
+
+/* HF Llama pre-attention step on fused qkv [B*S, (Hq+2Hkv)*hd]: half-split RoPE (cos/sin [max_pos, hd/2] f32,
+ * row = absolute position pos0+s), q scale folded, Q [B,Hq,Spad,hd]; K and V appended to the cache at
+ * positions pos0..pos0+S-1:  Kc [B,Hkv,Smax,hd], Vtc [B,Hkv,hd,Smax].
+ * If `pos_dev` != NULL the start position is read from device memory (pos_dev[0]) instead of pos0 (graph replay). */
+int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* sin, void* Q, void* Kc, void* Vtc,
+                     int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0, const int32_t* pos_dev,
+                     float q_scale, gar_stream_t stream);
+
+/* Flash-style attention (replaces F.scaled_dot_product_attention in timm AttentionRope and flash-attn-2 /
+ * eager attention in HF Llama, modeling_gar.py:40-43). Q [B,Hq,q_pad,hd] (pre-scaled by scale*log2e),
+ * K [B,Hkv,kv_stride,hd], Vt [B,Hkv,hd,kv_stride] (entries beyond kv_len must be finite); O [B*q_len, Hq*hd]
+ * token-major. causal: query i attends kv j <= i + (kv_len - q_len).
+ * If `kv_len_dev` != NULL the kv length is read from device memory (decode step inside a replayed graph). */
+int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd,
+                  int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
+                  gar_stream_t stream);
+
+/* PerceptionLMAdaptiveAvgPooling (modeling_perception_lm.py:47-60): per tile [g*g, C] -> [(g/2)^2, C], exact 2x2
+ * mean. Input tile t starts at row t*in_tile_tokens + in_token_offset of x (lets the projector run over the
+ * cls-inclusive token matrix and drop the cls row here, modeling_perception_lm.py:263-264). */
+int gar_pool2x2(int dtype, const void* x, void* y, int T, int g, int C, int in_tile_tokens, int in_token_offset,
+                gar_stream_t stream);
+
+/* get_placeholder_mask + crop-token span search (modeling_perception_lm.py:271-331, modeling_gar.py:356-360),
+ * sync-free: slot[s] = rank of s among image tokens of its row or -1; counts[b] = #image tokens;
+ * spans[b][c] = (min index, max index) of crop token c or (-1,-1). input_ids int64 [B,S]. */
+int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int64_t image_token_id, const int64_t* crop_ids,
+                         int n_crop, int32_t* slot, int32_t* counts, int32_t* spans, gar_stream_t stream);
+
+/* nn.Embedding + masked_scatter (modeling_gar.py:332,341-346): out[b,s,:] = slot<0 ? E[id] : feats[b][slot].
+ * feats [B, n_feat_rows, C] */
+int gar_embed_assemble(int dtype, const int64_t* input_ids, const int32_t* slot, const void* E, const void* feats,
+                       void* out, int B, int S, int C, int64_t n_feat_rows, int64_t vocab, gar_stream_t stream);
+
+/* RoI-aligned feature replay (modeling_gar.py:348-414 == _merge + torchvision.ops.roi_align(aligned=True,
+ * sampling_ratio=2) + permute/flatten/cast + splice), reading the pooled features in their TILE layout
+ * feats [tiles(incl. thumbnail), P*P, C] (no _merge copy, no fp32 copy of the map) and writing P*P rows of
+ * `embeds` [S, C] starting at spans[2*crop_index] (device) — skipped when the crop token is absent.
+ * roi = (x1,y1,x2,y2) in the reference's `roi_feat` coordinates, spatial_scale as passed to roi_align. */
+int gar_roi_replay(int dtype, const void* feats, void* embeds, const int32_t* spans, int crop_index, int first_tile,
+                   int ncw, int nch, int P, int C, int S, float rx1, float ry1, float rx2, float ry2,
+                   float spatial_scale, int sampling_ratio, int aligned, gar_stream_t stream);
+
+/* Decode-step helpers (HF GenerationMixin greedy loop, modeling_gar.py:418-426):
+ * embedding gather for the just-sampled tokens; argmax over logits with first-index tie break writing
+ * out_tokens[b*out_stride + step_dev[0]] and cur_tokens[b]; device-side counters (position / step) so one captured
+ * hipGraph replays for every token. */
+int gar_embed_lookup(int dtype, const int64_t* tokens, const void* E, void* out, int B, int C, int64_t vocab,
+                     gar_stream_t stream);
+int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
+               const int32_t* step_dev, int64_t* cur_tokens, void* workspace, gar_stream_t stream);
+int64_t gar_argmax_workspace(int B, int V);
+int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAR_HIP_H */

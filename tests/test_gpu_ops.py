@@ -1,0 +1,354 @@
+"""GPU (-m gpu): every HIP kernel behind the C ABI against a plain fp32/fp64 PyTorch-CPU statement of the same op
+or against the oracle, on seeded inputs. f32 mode = tight tolerance (exact-f32 MFMA, only summation order differs);
+bf16 mode = bf16-rounding tolerance; index / selection work is bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 1.6e-2
+
+
+def close(out, ref, dt, scale=None, extra=1.0):
+    out = out.detach().float().cpu().double()
+    ref = ref.detach().double().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    err = float((out - ref).abs().max())
+    assert err <= extra * tol(dt) * max(s, 1e-6) + 1e-6, f"max err {err} vs scale {s} ({dt})"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gar_amd import hip
+    hip.require_device(0)
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dt):
+    """value as the kernel sees it (bf16-rounded inputs are the reference's inputs too)"""
+    return x.to(dt).float()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1025, 384, 128), (17, 1000, 64), (5, 48, 256),
+                                   (16, 262, 128), (1, 64, 2048)])
+def test_gemm_plain_and_tails(dev, dt, M, N, K):
+    from gar_amd import hip, ops
+    if N % 16 and M > 16 and N % 4:
+        pytest.skip("general kernel needs N%4==0")
+    a, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=K ** -0.5), dt)
+    ldc = (N + 63) // 64 * 64
+    out = torch.full((M, ldc), 7.0, dtype=dt, device=dev)
+    ops.gemm(a.to(dev, dt), w.to(dev, dt), out)
+    ref = a.double() @ w.double().T
+    close(out[:, :N], ref, dt)
+    assert float((out[:, N:].float() - 7.0).abs().max()) == 0 if ldc > N else True
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [4, 200])
+def test_gemm_epilogues(dev, dt, M):
+    from gar_amd import hip, ops
+    N, K = 256, 128
+    a, w = q(rnd(M, K, seed=3), dt), q(rnd(N, K, seed=4, scale=K ** -0.5), dt)
+    bias, gamma, res = q(rnd(N, seed=5), dt), q(rnd(N, seed=6), dt), q(rnd(M, N, seed=7), dt)
+    A, W_ = a.to(dev, dt), w.to(dev, dt)
+    acc = a.double() @ w.double().T
+    out = torch.empty(M, N, dtype=dt, device=dev)
+    ops.gemm(A, W_, out, hip.EPI_BIAS, bias=bias.to(dev, dt))
+    close(out, acc + bias.double(), dt)
+    ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=bias.to(dev, dt))
+    close(out, F.gelu(acc + bias.double()), dt)
+    r = res.to(dev, dt).clone()
+    ops.gemm(A, W_, r, hip.EPI_BIAS_SCALE_RES, bias=bias.to(dev, dt), residual=r, gamma=gamma.to(dev, dt))   # in place
+    close(r, res.double() + gamma.double() * (acc + bias.double()), dt)
+    r = res.to(dev, dt).clone()
+    ops.gemm(A, W_, r, hip.EPI_RES, residual=r)
+    close(r, res.double() + acc, dt)
+    # SWIGLU with the [gate16|up16] interleave
+    Fd = N // 2
+    g_w, u_w = w[:Fd], w[Fd:]
+    gu = torch.stack([g_w.view(Fd // 16, 16, K), u_w.view(Fd // 16, 16, K)], 1).reshape(N, K)
+    o2 = torch.empty(M, Fd, dtype=dt, device=dev)
+    ops.gemm(A, gu.to(dev, dt), o2, hip.EPI_SWIGLU)
+    close(o2, F.silu(a.double() @ g_w.double().T) * (a.double() @ u_w.double().T), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_strided_rows(dev, dt):
+    from gar_amd import ops
+    B, S, Cc, N = 3, 10, 128, 64
+    h = q(rnd(B, S, Cc, seed=8), dt)
+    w = q(rnd(N, Cc, seed=9, scale=Cc ** -0.5), dt)
+    hd = h.to(dev, dt)
+    out = torch.empty(B, N, dtype=dt, device=dev)
+    ops.gemm(hd[:, S - 1, :], w.to(dev, dt), out)
+    close(out, h[:, S - 1].double() @ w.double().T, dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("D", [128, 1024, 2048, 4608])
+def test_norms(dev, dt, D):
+    from gar_amd import ops
+    M = 37
+    x = q(rnd(M, D, seed=10, scale=2.0) + 0.3, dt)
+    w, b = q(1 + 0.1 * rnd(D, seed=11), dt), q(0.1 * rnd(D, seed=12), dt)
+    y = torch.empty(M, D, dtype=dt, device=dev)
+    ops.layernorm(x.to(dev, dt), w.to(dev, dt), b.to(dev, dt), 1e-5, out=y)
+    close(y, F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5), dt)
+    ops.rmsnorm(x.to(dev, dt), w.to(dev, dt), 1e-5, out=y)
+    xd = x.double()
+    n = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5)
+    if dt == torch.bfloat16:
+        n = n.to(torch.bfloat16).double()
+    close(y, w.double() * n, dt)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+def test_patch_embed_with_mask_matches_two_convs(dev, dt):
+    """im2col + one GEMM (PATCH_POS epilogue) == patch_embed conv + mask conv + pos embed (oracle A1/A2/A4 head)."""
+    from gar_amd import hip, ops
+    from oracle import gar_oracle as O
+    T, img, patch, D, P = 3, 56, 14, 64, 5
+    g = img // patch
+    n = g * g
+    pix = q(rnd(T, 3, img, img, seed=13), dt)
+    ids = torch.randint(0, 8, (T, 1, img, img), generator=torch.Generator().manual_seed(14)).expand(T, 3, img, img)
+    mvals = q((ids.float() / 255.0 - 0.5) / 0.5, dt)
+    wp, wm = q(rnd(D, 3, patch, patch, seed=15, scale=0.05), dt), q(rnd(D, 3, patch, patch, seed=16, scale=0.05), dt)
+    pos = q(rnd(n + 1, D, seed=17, scale=0.2), dt)
+    Kp = (6 * patch * patch + 63) // 64 * 64
+    wcat = torch.zeros(D, Kp)
+    wcat[:, :3 * patch * patch] = wp.flatten(1)
+    wcat[:, 3 * patch * patch:6 * patch * patch] = wm.flatten(1)
+    A = torch.empty(T * n, Kp, dtype=dt, device=dev)
+    ops.patch_im2col(pix.to(dev, dt), mvals.to(dev, dt), A, patch, P)
+    x = torch.zeros(T, n + 1, D, dtype=dt, device=dev)
+    ops.gemm(A, wcat.to(dev, dt), x.view(T * (n + 1), D), hip.EPI_PATCH_POS, pos=pos.to(dev, dt), tokens_in=n,
+             tokens_out=n + 1, token_offset=1)
+    binary = O.decode_mask_values(mvals.to(dt), P)
+    assert binary.unique().tolist() == [0.0, 1.0]
+    ref = F.conv2d(pix.double(), wp.double(), stride=patch) + F.conv2d(binary.double(), wm.double(), stride=patch)
+    ref = ref.flatten(2).transpose(1, 2) + pos[1:].double()
+    close(x[:, 1:], ref, dt)
+    assert float(x[:, 0].float().abs().max()) == 0.0
+    # binary mask columns are exact
+    Ah = A.float().cpu().view(T, g, g, Kp)[..., 3 * patch * patch:6 * patch * patch].reshape(T, g, g, 3, patch, patch)
+    bref = binary.view(T, 3, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5)
+    assert torch.equal(Ah, bref)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pool2x2_with_cls_window(dev, dt):
+    from gar_amd import ops
+    T, g, Cc = 2, 8, 64
+    x = q(rnd(T, g * g + 1, Cc, seed=18), dt)
+    y = torch.empty(T, (g // 2) ** 2, Cc, dtype=dt, device=dev)
+    ops.pool2x2(x.to(dev, dt), y, g, in_tile_tokens=g * g + 1, in_token_offset=1)
+    ref = F.adaptive_avg_pool2d(x[:, 1:].double().permute(0, 2, 1).reshape(T, Cc, g, g), (g // 2, g // 2))
+    close(y, ref.flatten(2).transpose(1, 2), dt)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _attn_ref(qh, kh, vh, causal, off):
+    s = (qh.double() @ kh.double().transpose(-1, -2)) * (qh.shape[-1] ** -0.5)
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        m = torch.ones(Sq, Sk, dtype=torch.bool).tril(diagonal=off)
+        s = s.masked_fill(~m, float("-inf"))
+    return torch.softmax(s, -1) @ vh.double()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("N,npt", [(65, 1), (1025, 1), (200, 0)])
+def test_vit_attention_path(dev, dt, N, npt):
+    """qkv_post (interleaved 2-D RoPE, relayout, Vt) + non-causal attention vs the oracle's AttentionRope math."""
+    from gar_amd import ops
+    from oracle import gar_oracle as O
+    T, H, hd = 2, 2, 64
+    D = H * hd
+    Npad = (N + 63) // 64 * 64
+    qkv = q(rnd(T * N, 3 * D, seed=19), dt)
+    sin, cos = rnd(N - npt, hd, seed=20).sin(), rnd(N - npt, hd, seed=21).cos()
+    Q = torch.full((T, H, Npad, hd), float("nan"), dtype=dt, device=dev)
+    K = torch.full((T, H, Npad, hd), float("nan"), dtype=dt, device=dev)
+    Vt = torch.full((T, H, hd, Npad), float("nan"), dtype=dt, device=dev)
+    out = torch.empty(T * N, D, dtype=dt, device=dev)
+    ops.vit_qkv_post(qkv.to(dev, dt), sin.to(dev), cos.to(dev), Q, K, Vt, T, N, npt, H, hd, Npad,
+                     (hd ** -0.5) * 1.4426950408889634)
+    ops.attention(Q, K, Vt, out, T, H, H, hd, N, Npad, N, Npad, causal=False)
+    x = qkv.view(T, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qq, kk, vv = x.unbind(0)
+    rot = O._rot_interleaved
+    qq = torch.cat([qq[:, :, :npt], qq[:, :, npt:] * cos + rot(qq[:, :, npt:]) * sin], 2)
+    kk = torch.cat([kk[:, :, :npt], kk[:, :, npt:] * cos + rot(kk[:, :, npt:]) * sin], 2)
+    ref = _attn_ref(qq, kk, vv, False, 0).transpose(1, 2).reshape(T * N, D)
+    close(out, ref, dt, extra=2.0)
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("S", [70, 333])
+def test_llm_prefill_then_decode_attention(dev, dt, S):
+    """llm_qkv_post (half-split RoPE, GQA, cache append incl. transposed V) + causal prefill attention, then two
+    single-token decode steps with the kv length read from device memory."""
+    from gar_amd import ops
+    from oracle import gar_oracle as O
+    B, Hq, Hkv, hd = 2, 4, 2, 64
+    Smax = (S + 8 + 63) // 64 * 64
+    Wd = (Hq + 2 * Hkv) * hd
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = pos[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    Kc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
+    Vtc = torch.zeros(B, Hkv, hd, Smax, dtype=dt, device=dev)
+    scale = (hd ** -0.5) * 1.4426950408889634
+
+    def ref_qkv(x, p0):
+        Sx = x.shape[1]
+        xq = x[..., :Hq * hd].view(B, Sx, Hq, hd).transpose(1, 2)
+        xk = x[..., Hq * hd:(Hq + Hkv) * hd].view(B, Sx, Hkv, hd).transpose(1, 2)
+        xv = x[..., (Hq + Hkv) * hd:].view(B, Sx, Hkv, hd).transpose(1, 2)
+        c = torch.cat([cos, cos], -1)[p0:p0 + Sx]
+        s_ = torch.cat([sin, sin], -1)[p0:p0 + Sx]
+        return xq * c + O._rotate_half(xq) * s_, xk * c + O._rotate_half(xk) * s_, xv
+
+    qkv = q(rnd(B, S, Wd, seed=22), dt)
+    Spad = (S + 63) // 64 * 64
+    Q = torch.empty(B, Hq, Spad, hd, dtype=dt, device=dev)
+    out = torch.empty(B * S, Hq * hd, dtype=dt, device=dev)
+    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax,
+                     0, None, scale)
+    ops.attention(Q, Kc, Vtc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
+    rq, rk, rv = ref_qkv(qkv, 0)
+    rep = Hq // Hkv
+    ref = _attn_ref(rq, rk.repeat_interleave(rep, 1), rv.repeat_interleave(rep, 1), True, 0)
+    close(out, ref.transpose(1, 2).reshape(B * S, Hq * hd), dt, extra=2.0)
+    close(Kc[:, :, :S], rk, dt)
+    close(Vtc[:, :, :, :S], rv.transpose(-1, -2), dt)
+    # decode
+    counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
+    Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
+    o1 = torch.empty(B, Hq * hd, dtype=dt, device=dev)
+    ks, vs = [rk], [rv]
+    for step in range(2):
+        x1 = q(rnd(B, 1, Wd, seed=23 + step), dt)
+        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vtc, B, 1, 1, Hq, Hkv, hd, Smax,
+                         0, counters[0:1], scale)
+        ops.attention(Q1, Kc, Vtc, o1, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False, kv_len_dev=counters[1:2])
+        ops.counter_add(counters, 1)
+        q1, k1, v1 = ref_qkv(x1, S + step)
+        ks.append(k1)
+        vs.append(v1)
+        kk, vv = torch.cat(ks, 2), torch.cat(vs, 2)
+        r1 = _attn_ref(q1, kk.repeat_interleave(rep, 1), vv.repeat_interleave(rep, 1), False, 0)
+        close(o1, r1.transpose(1, 2).reshape(B, Hq * hd), dt, extra=2.0)
+    assert counters.tolist() == [S + 2, S + 3]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_placeholder_scan_and_assemble(dev):
+    from gar_amd import ops
+    B, S, Cc, V = 2, 2500, 64, 400
+    g = torch.Generator().manual_seed(30)
+    ids = torch.randint(0, 290, (B, S), generator=g)
+    img_tok, crops = 300, [304, 305, 308, 310, 311]
+    ids[0, 5:5 + 1200] = img_tok
+    ids[1, 100:900] = img_tok
+    ids[1, 1000:1400] = img_tok
+    ids[0, 1300:1316] = 305
+    ids[1, 1500:1516] = 310
+    ids[1, 1600:1616] = 304
+    slot = torch.empty(B, S, dtype=torch.int32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    spans = torch.empty(B, 5, 2, dtype=torch.int32, device=dev)
+    ops.placeholder_scan(ids.to(dev), img_tok, torch.tensor(crops, device=dev), slot, counts, spans)
+    m = ids == img_tok
+    ref_slot = torch.where(m, m.cumsum(1) - 1, torch.full_like(ids, -1)).int()
+    assert torch.equal(slot.cpu(), ref_slot)
+    assert counts.tolist() == [1200, 1200]
+    assert spans.cpu().tolist() == [[[-1, -1], [1300, 1315], [-1, -1], [-1, -1], [-1, -1]],
+                                    [[1600, 1615], [-1, -1], [-1, -1], [1500, 1515], [-1, -1]]]
+    for dt in DT:
+        E, feats = q(rnd(V, Cc, seed=31), dt), q(rnd(B, 1200, Cc, seed=32), dt)
+        out = torch.empty(B, S, Cc, dtype=dt, device=dev)
+        ops.embed_assemble(ids.to(dev), slot, E.to(dev, dt), feats.to(dev, dt), out, 1200)
+        ref = F.embedding(ids, E)
+        ref = ref.masked_scatter(m.unsqueeze(-1).expand_as(ref), feats)
+        assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("bbox", [(0.720703125, 0.8688311688311688, 0.7939453125, 0.9233766233766234),
+                                  (0.0, 0.0, 1.0, 1.0), (0.3, 0.55, 0.31, 0.56), (0.02, 0.5, 0.35, 0.78)])
+def test_roi_replay_bit_exact_vs_oracle(dev, dt, bbox):
+    """replay kernel == oracle feature_replay (merge + fp32 roi_align + cast + splice), bit for bit."""
+    from gar_amd import GARConfig, ops
+    from oracle import gar_oracle as O
+    cfg = GARConfig.gar_1b()
+    P, Cc, ncw, nch = 16, 64, 3, 2
+    tiles = ncw * nch + 1
+    feats = q(rnd(tiles, P * P, Cc, seed=33), dt)
+    S = 700
+    ids = torch.full((1, S), 7, dtype=torch.int64)
+    ids[0, 100:356] = 128005
+    emb = q(rnd(1, S, Cc, seed=34), dt)
+    ref = O.feature_replay(emb.to(dt), ids, feats.to(dt), torch.tensor([[ncw, nch]]), [{"128005": bbox}], cfg)
+    spans = torch.tensor([[-1, -1], [100, 355], [-1, -1], [-1, -1], [-1, -1]], dtype=torch.int32, device=dev)
+    e = emb.to(dev, dt).clone()
+    roi, ss = O.replay_roi(bbox, P * nch, P * ncw, cfg.feat_stride)
+    ops.roi_replay(feats.to(dev, dt), e[0], spans, 1, 1, ncw, nch, P, Cc, S, roi[1:], ss, 2, True)
+    assert torch.equal(e.float().cpu(), ref.float())
+    # absent crop token: nothing is written
+    e2 = emb.to(dev, dt).clone()
+    ops.roi_replay(feats.to(dev, dt), e2[0], spans, 0, 1, ncw, nch, P, Cc, S, roi[1:], ss, 2, True)
+    assert torch.equal(e2.float().cpu(), emb)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_argmax_first_index_tiebreak_and_lookup(dev, dt):
+    from gar_amd import ops
+    B, V, Cc = 3, 128262, 128
+    lg = q(rnd(B, V, seed=35), dt)
+    lg[0, 777] = 50.0
+    lg[0, 90000] = 50.0           # tie -> first index
+    lg[1, V - 1] = 60.0
+    lg[2, 0] = 70.0
+    ld = (V + 63) // 64 * 64
+    L = torch.full((B, ld), 1000.0, dtype=dt, device=dev)   # padding columns must be ignored
+    L[:, :V] = lg.to(dev, dt)
+    out = torch.zeros(B, 4, dtype=torch.int64, device=dev)
+    cur = torch.zeros(B, dtype=torch.int64, device=dev)
+    step = torch.tensor([2], dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.argmax_workspace(B, V), dtype=torch.uint8, device=dev)
+    ops.argmax(L, V, out, 4, step, cur, ws)
+    assert cur.tolist() == [777, V - 1, 0] and out[:, 2].tolist() == [777, V - 1, 0]
+    assert torch.equal(cur.cpu(), lg.argmax(-1))
+    E = q(rnd(1000, Cc, seed=36), dt)
+    h = torch.empty(B, Cc, dtype=dt, device=dev)
+    ops.embed_lookup(torch.tensor([5, 999, 0], device=dev), E.to(dev, dt), h)
+    assert torch.equal(h.float().cpu(), E[[5, 999, 0]])
+
+
+def test_abi_errors_are_reported_not_thrown(dev):
+    from gar_amd import hip, ops
+    a = torch.zeros(4, 60, device=dev)
+    w = torch.zeros(16, 60, device=dev)
+    with pytest.raises(hip.GarError, match="K=60"):
+        ops.gemm(a, w, torch.zeros(4, 16, device=dev))

@@ -156,3 +156,26 @@ def test_end_to_end_tiny_runs_and_is_deterministic():
     b = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], s["aspect_ratios"], s["bboxes"],
                        s["input_ids"], s["attention_mask"], max_new_tokens=6, attn_impl="sdpa")
     assert a.shape == (1, 6) and a.tolist() == b.tolist()
+
+
+def test_numpy_roi_align_equals_c_restatement_bitwise():
+    """Two independent restatements of torchvision's CPU kernel (numpy in gar_oracle.py, plain C in roi_align_ref.c)
+    agree bit for bit, including the reference's double-scaled call (spatial_scale = 1/28 on feature coordinates)."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    lib = ctypes.CDLL(os.path.join(root, "oracle", "libroi_align_ref.so"))
+    g = torch.Generator().manual_seed(5)
+    C, H, Wd = 7, 32, 48
+    fm = torch.randn(1, C, H, Wd, generator=g)
+    for roi, ss, aligned in [([0, 12.3, 20.1, 40.7, 30.9], 1 / 28, True), ([0, 1.0, 2.0, 30.0, 25.0], 1.0, True),
+                             ([0, 5.5, 3.25, 6.0, 3.5], 0.5, False), ([0, -50.0, -50.0, 900.0, 700.0], 1 / 14, True)]:
+        rois = torch.tensor([roi], dtype=torch.float32)
+        a = O.roi_align(fm, rois, (16, 16), ss, 2, aligned)
+        out = np.zeros((1, C, 16, 16), dtype=np.float32)
+        acc = np.zeros(C, dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        lib.roi_align_ref(fm.numpy().ctypes.data_as(fp), C, H, Wd, rois.numpy().ctypes.data_as(fp), 1, 16, 16,
+                          ctypes.c_float(ss), 2, int(aligned), out.ctypes.data_as(fp), acc.ctypes.data_as(fp))
+        assert np.array_equal(a.numpy(), out), (roi, ss)
