@@ -94,6 +94,51 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
     }
 }
 
+// decode (S == 1): one thread per (batch, head, 8-wide slice of the first half) — a single small launch.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __restrict__ qkv, const float* __restrict__ cs,
+                                                                  const float* __restrict__ sn, T* __restrict__ Q,
+                                                                  T* __restrict__ Kc, T* __restrict__ Vtc, int B, int Spad,
+                                                                  int Hq, int Hkv, int Smax, int pos0,
+                                                                  const int32_t* __restrict__ pos_dev, float q_scale) {
+    constexpr int HALF = HD / 2, LPH = HALF / 8;
+    const int nh = Hq + 2 * Hkv;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * nh * LPH) return;
+    const int i8 = (idx % LPH) * 8;
+    const int head = (idx / LPH) % nh;
+    const int b = idx / (LPH * nh);
+    const int p0 = pos_dev ? pos_dev[0] : pos0;
+    const T* row = qkv + (int64_t)b * nh * HD + head * HD;
+    float x1[8], x2[8];
+    ld8(row + i8, x1);
+    ld8(row + HALF + i8, x2);
+    if (head < Hq + Hkv) {
+        const float* cp = cs + (int64_t)p0 * HALF + i8;
+        const float* sp = sn + (int64_t)p0 * HALF + i8;
+        const float sc = head < Hq ? q_scale : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = cp[e], sv = sp[e];
+            const float o1 = x1[e] * c + (-x2[e]) * sv;
+            const float o2 = x2[e] * c + x1[e] * sv;
+            x1[e] = o1 * sc;
+            x2[e] = o2 * sc;
+        }
+        T* o = head < Hq ? Q + (((int64_t)b * Hq + head) * Spad) * HD
+                         : Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0) * HD;
+        st8(o + i8, x1);
+        st8(o + HALF + i8, x2);
+    } else {
+        T* vbase = Vtc + ((int64_t)b * Hkv + (head - Hq - Hkv)) * HD * (int64_t)Smax + p0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            DT<T>::st(vbase + (int64_t)(i8 + e) * Smax, x1[e]);
+            DT<T>::st(vbase + (int64_t)(HALF + i8 + e) * Smax, x2[e]);
+        }
+    }
+}
+
 extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, const float* sn, void* Q, void* Kc,
                                 void* Vtc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
                                 const int32_t* pos_dev, float q_scale, gar_stream_t stream) {
@@ -101,9 +146,21 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
     GAR_CHECK_ARG(B > 0 && S > 0 && Spad >= S && Smax % 64 == 0, "llm_qkv_post: bad shape");
     GAR_CHECK_ARG(pos_dev || pos0 + S <= Smax, "llm_qkv_post: cache overflow %d+%d > %d", pos0, S, Smax);
     GAR_CHECK_ARG(hd == 64 || hd == 128, "llm_qkv_post: head_dim %d not built (64, 128)", hd);
-    dim3 grid(B * ((Spad + 63) / 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_LQP(TT, HD_)                                                                                         \
+    if (S == 1) {
+        const int total = B * (Hq + 2 * Hkv) * (hd / 16);
+        dim3 g1((total + 255) / 256), b1(256);
+#define LAUNCH_LQD(TT, HD_)                                                                                         \
+    hipLaunchKernelGGL((llm_qkv_post_decode_kernel<TT, HD_>), g1, b1, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc, \
+                       (TT*)Vtc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, q_scale)
+        if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQD(bf16_t, 64); else LAUNCH_LQD(bf16_t, 128); }
+        else { if (hd == 64) LAUNCH_LQD(float, 64); else LAUNCH_LQD(float, 128); }
+#undef LAUNCH_LQD
+        GAR_CHECK_LAUNCH();
+        return GAR_OK;
+    }
+    dim3 grid(B * ((Spad + 63) / 64)), block(256);
+#define LAUNCH_LQP(TT, HD_)                                                                                       \
     hipLaunchKernelGGL((llm_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc,  \
                        (TT*)Vtc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, q_scale)
     if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQP(bf16_t, 64); else LAUNCH_LQP(bf16_t, 128); }

@@ -24,7 +24,7 @@ class GemmParams(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("gamma", C.c_void_p), ("pos", C.c_void_p), ("tokens_in", C.c_int32), ("tokens_out", C.c_int32),
-                ("token_offset", C.c_int32), ("reserved", C.c_int32)]
+                ("token_offset", C.c_int32), ("norm_eps", C.c_float), ("norm_w", C.c_void_p)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -40,7 +40,9 @@ SIGNATURES = {
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp], _i),
     "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
-    "gar_pool2x2": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
+    "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
+    "gar_pool2x2":([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "gar_embed_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp], _i),
     "gar_roi_replay": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _vp], _i),

@@ -337,8 +337,11 @@ class GARModel:
         Vld = _round_up(V, 64)
         logits = self._buf(key, "logits", (B, Vld))
         ws = self._buf(key, "amws", (ops.argmax_workspace(B, V),), torch.uint8)
-        ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
-        ops.gemm(xn, self.lm_head, logits)
+        if B <= 16:
+            ops.gemm(last_rows, self.lm_head, logits, norm_w=self.final_norm, norm_eps=t.rms_norm_eps)
+        else:
+            ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
+            ops.gemm(xn, self.lm_head, logits)
         ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], st["cur"], ws)
         return logits
 
@@ -356,16 +359,25 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
+        # enough (split, kv head, batch) waves to cover the chip: ~2048 single-wave blocks
+        nsplit = max(1, min(64, 2048 // max(1, B * Hkv)))
+        dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
+        fuse = B <= 16                      # RMSNorm folded into the skinny GEMM prologue (no separate launch)
         for li, ly in enumerate(self.layers):
-            ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
-            ops.gemm(xn, ly["qkv"], qkv)
+            if fuse:
+                ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
+            else:
+                ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["qkv"], qkv)
             ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale)
-            ops.attention(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False,
-                          kv_len_dev=kvlen_dev)
+            ops.attention_decode(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws)
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
-            ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
-            ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+            if fuse:
+                ops.gemm(h, ly["gu"], ff, hip.EPI_SWIGLU, norm_w=ly["ln2"], norm_eps=t.rms_norm_eps)
+            else:
+                ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
             ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         logits = self._head(h, B, out_tokens, st)
         ops.counter_add(st["counters"][0:3], 1)

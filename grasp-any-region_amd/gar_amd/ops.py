@@ -23,7 +23,8 @@ def _chk(t: torch.Tensor, name: str):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, bias=None, residual=None,
-         gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0):
+         gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0, norm_w=None,
+         norm_eps: float = 0.0):
     """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(-1) == 1
@@ -42,6 +43,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     p.gamma = ptr(gamma)
     p.pos = ptr(pos)
     p.tokens_in, p.tokens_out, p.token_offset = tokens_in, tokens_out, token_offset
+    p.norm_w, p.norm_eps = ptr(norm_w), norm_eps
     prof = KERNEL_TIMERS
     if prof is not None and not torch.cuda.is_current_stream_capturing():
         # HIP events on the launch stream around this one kernel (bench.py roofline; never inside graph capture)
@@ -112,6 +114,15 @@ def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0,
 def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None):
     check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
                               kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention")
+
+
+def attention_decode(q, Kc, Vtc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace):
+    check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vtc), ptr(O), B, Hq, Hkv, hd, Smax,
+                                     ptr(kv_len_dev), max_splits, ptr(workspace), stream()), "gar_attention_decode")
+
+
+def attention_decode_workspace(B, Hq, hd, max_splits) -> int:
+    return int(lib().gar_attention_decode_workspace(B, Hq, hd, max_splits))
 
 
 def pool2x2(x, y, g: int, in_tile_tokens: int = 0, in_token_offset: int = 0):

@@ -65,7 +65,9 @@ typedef struct gar_gemm_params {
     const void* gamma;                 /* [N]                                                      */
     const void* pos;                   /* PATCH_POS: [tokens_out, N]                               */
     int32_t tokens_in, tokens_out, token_offset;
-    int32_t reserved;
+    float norm_eps;                    /* with norm_w: rsqrt(mean(x^2) + norm_eps)                  */
+    const void* norm_w;                /* [K] or NULL; M <= 16 only: C = epilogue(RMSNorm(A; norm_w) W^T), i.e. the */
+                                       /* HF LlamaRMSNorm in front of q/k/v, gate/up and lm_head fused into the GEMM */
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -114,6 +116,15 @@ int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* 
 int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd,
                   int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                   gar_stream_t stream);
+
+/* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
+ * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / Vt.
+ * q [B,Hq,hd] pre-scaled; kv length = kv_len_dev[0] (device memory, so one captured hipGraph replays for every
+ * token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes. GAR_F32 routes to gar_attention. */
+int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits);
+int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq, int Hkv,
+                         int hd, int Smax, const int32_t* kv_len_dev, int max_splits, void* workspace,
+                         gar_stream_t stream);
 
 /* PerceptionLMAdaptiveAvgPooling (modeling_perception_lm.py:47-60): per tile [g*g, C] -> [(g/2)^2, C], exact 2x2
  * mean. Input tile t starts at row t*in_tile_tokens + in_token_offset of x (lets the projector run over the

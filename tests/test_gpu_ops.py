@@ -252,6 +252,12 @@ def test_llm_prefill_then_decode_attention(dev, dt, S):
         ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vtc, B, 1, 1, Hq, Hkv, hd, Smax,
                          0, counters[0:1], scale)
         ops.attention(Q1, Kc, Vtc, o1, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False, kv_len_dev=counters[1:2])
+        o2s = []
+        for nsplit in (1, 3, 16):       # split-KV decode kernel (bf16) / routed to the same f32 kernel in parity mode
+            ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, nsplit), dtype=torch.uint8, device=dev)
+            o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
+            ops.attention_decode(Q1, Kc, Vtc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws)
+            o2s.append(o2)
         ops.counter_add(counters, 1)
         q1, k1, v1 = ref_qkv(x1, S + step)
         ks.append(k1)
@@ -259,6 +265,8 @@ def test_llm_prefill_then_decode_attention(dev, dt, S):
         kk, vv = torch.cat(ks, 2), torch.cat(vs, 2)
         r1 = _attn_ref(q1, kk.repeat_interleave(rep, 1), vv.repeat_interleave(rep, 1), False, 0)
         close(o1, r1.transpose(1, 2).reshape(B, Hq * hd), dt, extra=2.0)
+        for o2 in o2s:
+            close(o2, r1.transpose(1, 2).reshape(B, Hq * hd), dt, extra=2.0)
     assert counters.tolist() == [S + 2, S + 3]
 
 
@@ -344,6 +352,30 @@ def test_argmax_first_index_tiebreak_and_lookup(dev, dt):
     h = torch.empty(B, Cc, dtype=dt, device=dev)
     ops.embed_lookup(torch.tensor([5, 999, 0], device=dev), E.to(dev, dt), h)
     assert torch.equal(h.float().cpu(), E[[5, 999, 0]])
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("epi", ["none", "swiglu"])
+def test_skinny_gemm_with_fused_rmsnorm(dev, dt, epi):
+    """decode path: RMSNorm folded into the weight-streaming GEMM (x*g as operand, rstd applied to the accumulator)."""
+    from gar_amd import hip, ops
+    M, K, N = 6, 2048, 512
+    x = q(rnd(M, K, seed=40, scale=3.0), dt)
+    g = q(1 + 0.1 * rnd(K, seed=41), dt)
+    w = q(rnd(N, K, seed=42, scale=K ** -0.5), dt)
+    xd = x.double()
+    n = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * g.double()
+    if epi == "none":
+        out = torch.empty(M, N, dtype=dt, device=dev)
+        ops.gemm(x.to(dev, dt), w.to(dev, dt), out, norm_w=g.to(dev, dt), norm_eps=1e-5)
+        close(out, n @ w.double().T, dt, extra=2.0)
+    else:
+        Fd = N // 2
+        gw, uw = w[:Fd], w[Fd:]
+        gu = torch.stack([gw.view(Fd // 16, 16, K), uw.view(Fd // 16, 16, K)], 1).reshape(N, K)
+        out = torch.empty(M, Fd, dtype=dt, device=dev)
+        ops.gemm(x.to(dev, dt), gu.to(dev, dt), out, hip.EPI_SWIGLU, norm_w=g.to(dev, dt), norm_eps=1e-5)
+        close(out, F.silu(n @ gw.double().T) * (n @ uw.double().T), dt, extra=2.0)
 
 
 def test_abi_errors_are_reported_not_thrown(dev):
