@@ -84,6 +84,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7) without the 1+erf cancellation: gelu(x) = max(x,0) - |x|/2 * poly(t) * exp(-x^2/2)
+// (bf16 kernels only; the f32 parity kernels keep erff)
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = exp2f(-z * z * 1.4426950408889634f);
+    return fmaxf(x, 0.f) - 0.5f * ax * poly * e;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 // ---- host side -----------------------------------------------------------------------------------------------

@@ -1,85 +1,20 @@
 // GEMM C[M,N] = A[M,K] * W[N,K]^T with fused epilogues — gfx950 MFMA kernels.
 //
+//   gemm_bf16_pp_kernel (gemm_pp.hip)  large problems: persistent 256x256x64 ping-pong kernel.
 //   gemm_bf16_kernel   128x128x64 tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, operands staged HBM->LDS by
 //                      global_load_lds (16 B/lane, no VGPR round trip), LDS image XOR-swizzled through the *source*
 //                      address (the DMA destination is lane-linear), double-buffered, one barrier per K tile.
 //   gemm_f32_kernel    parity mode: 64x64x16 tile on v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
 //   skinny_*_kernel    M <= 16 (decode): weight-streaming, W fragments loaded straight to VGPRs in full 128-B lines,
-//                      split-K across the waves of a block, LDS reduce.
+//                      split-K across the waves of a block, LDS reduce, optional fused RMSNorm prologue.
 //
 // The MFMA operands are swapped (A-operand = W rows, B-operand = A rows) so each lane ends up holding four
 // CONSECUTIVE output columns of one output row: bias/gamma/residual/stores are 8- or 16-byte vectors.
-#include "common.h"
+#include <stdlib.h>
 
-#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+#include "gemm_epilogue.h"
 
-// ---------------------------------------------------------------------------------------------------------------
-// epilogue shared by all kernels: `v` = 4 accumulators for row m, columns n..n+3 (n % 4 == 0)
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store(const gar_gemm_params& p, int m, int n, float (&v)[4]) {
-    T* C = (T*)p.C;
-    if (EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES) {
-        float b[4];
-        ld4((const T*)p.bias + n, b);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += b[r];
-    }
-    if (EPI == GAR_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-    }
-    if (EPI == GAR_EPI_BIAS_SCALE_RES) {
-        float g[4], res[4];
-        ld4((const T*)p.gamma + n, g);
-        ld4((const T*)p.residual + (int64_t)m * p.ldr + n, res);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = res[r] + g[r] * v[r];
-    }
-    if (EPI == GAR_EPI_RES) {
-        float res[4];
-        ld4((const T*)p.residual + (int64_t)m * p.ldr + n, res);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = res[r] + v[r];
-    }
-    int64_t off;
-    if (EPI == GAR_EPI_PATCH_POS) {
-        int tile = m / p.tokens_in;
-        int tok = p.token_offset + (m - tile * p.tokens_in);
-        float pe[4];
-        ld4((const T*)p.pos + (int64_t)tok * p.N + n, pe);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += pe[r];
-        off = ((int64_t)tile * p.tokens_out + tok) * p.ldc + n;
-    } else {
-        off = (int64_t)m * p.ldc + n;
-    }
-    const int ncols = (EPI == GAR_EPI_SWIGLU) ? (p.N >> 1) : p.N;
-    if (n + 3 < ncols && ((off * (int64_t)sizeof(T)) & (sizeof(T) * 4 - 1)) == 0) {
-        st4(C + off, v);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < ncols) DT<T>::st(C + off + r, v[r]);
-    }
-}
-
-// XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run of tiles (bijective
-// for any grid size) and walk the run in groups of GM row-panels so neighbouring blocks share A/W panels in that L2.
-__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GM = 8;
-    const int gsz = GM * tiles_n;
-    const int g = wg / gsz;
-    const int first_m = g * GM;
-    const int gm = min(tiles_m - first_m, GM);
-    const int in = wg - g * gsz;
-    tm = first_m + in % gm;
-    tn = in / gm;
-}
+bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s);   // gemm_pp.hip
 
 // ===============================================================================================================
 // bf16: 128 x 128 x 64
@@ -109,7 +44,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | W 16K]
     int tm, tn;
-    tile_of_block(tiles_m, tiles_n, tm, tn);
+    tile_of(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,12 +320,12 @@ __global__ __launch_bounds__(1024) void skinny_f32_kernel(const gar_gemm_params 
     const int n0 = blockIdx.x * 16 * NT;
     const float* W = (const float*)p.W;
     const float* X = (const float*)p.A;
+    const float* Gw = (const float*)p.norm_w;
     const int ksteps = p.K / 16;
     const int per = (ksteps + nw - 1) / nw;
     const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
     const bool xvalid = frow < p.M;
     const float* xp = X + (int64_t)(xvalid ? frow : 0) * p.lda + fq * 4;
-    const float* Gw = (const float*)p.norm_w;
     float ssq = 0.f;
     const float* wp[NT];
 #pragma unroll
@@ -492,6 +427,7 @@ static int launch(int dtype, const gar_gemm_params& p, hipStream_t s) {
         return GAR_OK;
     }
     if (dtype == GAR_BF16) {
+        if (gar_gemm_pp_try(p, s)) return GAR_OK;
         const int tmn = (p.M + BM - 1) / BM, tnn = (p.N + BN - 1) / BN;
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tmn * tnn), dim3(256), 4 * TILE_BYTES, s, p, tmn, tnn);
     } else {

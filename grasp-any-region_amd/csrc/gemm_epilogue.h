@@ -1,0 +1,125 @@
+// Epilogues and tile mapping shared by the GEMM kernels.
+#pragma once
+#include "common.h"
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// `v` = 4 accumulators of row m, columns n..n+3 (n % 4 == 0)
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_store(const gar_gemm_params& p, int m, int n, float (&v)[4]) {
+    T* C = (T*)p.C;
+    if (EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES) {
+        float b[4];
+        ld4((const T*)p.bias + n, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+    }
+    if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_fast(v[r]) : gelu_erf(v[r]);
+    }
+    if (EPI == GAR_EPI_BIAS_SCALE_RES) {
+        float g[4], res[4];
+        ld4((const T*)p.gamma + n, g);
+        ld4((const T*)p.residual + (int64_t)m * p.ldr + n, res);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = res[r] + g[r] * v[r];
+    }
+    if (EPI == GAR_EPI_RES) {
+        float res[4];
+        ld4((const T*)p.residual + (int64_t)m * p.ldr + n, res);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = res[r] + v[r];
+    }
+    int64_t off;
+    if (EPI == GAR_EPI_PATCH_POS) {
+        int tile = m / p.tokens_in;
+        int tok = p.token_offset + (m - tile * p.tokens_in);
+        float pe[4];
+        ld4((const T*)p.pos + (int64_t)tok * p.N + n, pe);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += pe[r];
+        off = ((int64_t)tile * p.tokens_out + tok) * p.ldc + n;
+    } else {
+        off = (int64_t)m * p.ldc + n;
+    }
+    const int ncols = (EPI == GAR_EPI_SWIGLU) ? (p.N >> 1) : p.N;
+    if (n + 3 < ncols && ((off * (int64_t)sizeof(T)) & (sizeof(T) * 4 - 1)) == 0) {
+        st4(C + off, v);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < ncols) DT<T>::st(C + off + r, v[r]);
+    }
+}
+
+// 8 consecutive columns (n % 8 == 0): 16-byte bias / gamma / residual loads and one 16-byte store when aligned,
+// otherwise two 4-wide pieces. Not used with SWIGLU.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_store8(const gar_gemm_params& p, int m, int n, float (&v)[8]) {
+    int64_t off;
+    int tok = 0;
+    if (EPI == GAR_EPI_PATCH_POS) {
+        const int tile = m / p.tokens_in;
+        tok = p.token_offset + (m - tile * p.tokens_in);
+        off = ((int64_t)tile * p.tokens_out + tok) * p.ldc + n;
+    } else {
+        off = (int64_t)m * p.ldc + n;
+    }
+    const bool fast = n + 7 < p.N && ((off * (int64_t)sizeof(T)) & (sizeof(T) * 8 - 1)) == 0 &&
+                      ((EPI != GAR_EPI_BIAS_SCALE_RES && EPI != GAR_EPI_RES) ||
+                       ((((int64_t)m * p.ldr + n) * (int64_t)sizeof(T)) & (sizeof(T) * 8 - 1)) == 0);
+    if (!fast) {
+        float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        if (n < p.N) epilogue_store<T, EPI>(p, m, n, a);
+        if (n + 4 < p.N) epilogue_store<T, EPI>(p, m, n + 4, b);
+        return;
+    }
+    if (EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES) {
+        float b[8];
+        ld8((const T*)p.bias + n, b);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += b[r];
+    }
+    if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = sizeof(T) == 2 ? gelu_fast(v[r]) : gelu_erf(v[r]);
+    }
+    if (EPI == GAR_EPI_BIAS_SCALE_RES) {
+        float g[8], res[8];
+        ld8((const T*)p.gamma + n, g);
+        ld8((const T*)p.residual + (int64_t)m * p.ldr + n, res);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = res[r] + g[r] * v[r];
+    }
+    if (EPI == GAR_EPI_RES) {
+        float res[8];
+        ld8((const T*)p.residual + (int64_t)m * p.ldr + n, res);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = res[r] + v[r];
+    }
+    if (EPI == GAR_EPI_PATCH_POS) {
+        float pe[8];
+        ld8((const T*)p.pos + (int64_t)tok * p.N + n, pe);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += pe[r];
+    }
+    st8((T*)p.C + off, v);
+}
+
+// XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run of tiles (bijective
+// for any count) and walk the run in groups of GM row-panels so neighbouring blocks share A/W panels in that L2.
+// `v` = virtual block id in [0, nwg).
+__device__ __forceinline__ void tile_of(int v, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    const int GM = 8;
+    const int gsz = GM * tiles_n;
+    const int g = wg / gsz;
+    const int first_m = g * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int in = wg - g * gsz;
+    tm = first_m + in % gm;
+    tn = in / gm;
+}

@@ -1,0 +1,276 @@
+// bf16 "ping-pong" GEMM: 256 x 256 x 64 tiles, 8 waves (2 M x 4 N, 128 x 64 per wave), ONE persistent workgroup per
+// CU (128 KiB LDS), v_mfma_f32_16x16x32_bf16.
+//
+// Wave rows (wm = 0 / 1) share the four SIMDs of the CU and run the SAME instruction stream shifted by one barrier
+// interval (row 1 executes one extra s_barrier up front): in every interval one row issues the 16 MFMAs of a phase
+// while the other issues the ds_reads / global_load_lds of its next phase, so each SIMD's matrix pipe always has
+// exactly one wave feeding it and LDS / VMEM issue hides behind MFMAs.
+//
+//   K tile = 4 phases: (A0,B0) (B1) (A1) (B0)     A0/A1 = m-tiles 0-3 / 4-7 of the wave, B0/B1 = n-tiles 0-1 / 2-3
+//   staging: the next K tile (of this output tile, or K tile 0 of the NEXT output tile of the persistent loop) is
+//     DMA'd with global_load_lds (lane-linear LDS image, XOR swizzle applied to the SOURCE address) into the other
+//     stage during phase 0 (both A halves) and phase 1 (both W halves) — >= 2 intervals after the last ds_read of
+//     that stage (WAR) — and waited for with vmcnt(0) right before the last barrier of the K tile that both rows
+//     share, ~5 intervals after issue (RAW). Because the next output tile's first K tile is already in LDS when the
+//     epilogue starts, the epilogue's stores drain into L2/HBM underneath the next tile's main loop.
+//   epilogue: the W rows of an n-tile pair are fed in a permuted order so that a lane ends up with EIGHT consecutive
+//     output columns: bias / LayerScale / residual loads and the store are 16-byte vectors (64-B segments per row).
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
+
+#define PBM 256
+#define PBK 64
+#define PHALF (128 * 128)             // 16 KiB: 128 rows x 64 bf16
+#define PSTAGE (4 * PHALF)            // [A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255]
+
+// swizzle keys (16-byte chunk index ^= key(row)), chosen per operand so its ds_read_b128 access sets are conflict-free:
+//   A halves and SWIGLU W halves: fragment rows are 16 consecutive rows            -> key = row & 7
+//   W halves otherwise: fragment rows are {8q + r + 4(j&1), q = 0..3, r = 0..3}     -> key = ((row>>3)&3)*2 + ((row>>1)&1)
+// One 128-row half = 16 chunks of 8 rows (1 KiB, one wave-instruction each); wave w stages chunks w and 8+w.
+// `buffer_load_dwordx4 ... lds` through a buffer descriptor: the per-lane part of the address is ONE 32-bit VGPR
+// (voff = byte offset of (row = 8*wave + lane/8, 16-B chunk (lane&7)^key) inside a tile), everything else is scalar,
+// and rows past the end of the tensor (M / N tails) are zero-filled by the descriptor's bounds check.
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base,
+                                           char* lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_AS(lds + (i * 8 + wave) * 1024), 16,
+                                                 voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
+}
+
+template <int EPI, bool PERMT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
+    constexpr bool PERM = PERMT && EPI != GAR_EPI_SWIGLU;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
+    const int total = tiles_m * tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nt = p.K / PBK;
+
+    f32x4 acc[8][4];
+    bf16x8 af[4][2], bq[2][2];        // current A sub-tile (4 m-tiles x 2 k-steps), current B sub-tile (2 n-tiles x 2)
+
+    const unsigned rbA = (unsigned)p.lda * 2u, rbW = (unsigned)p.ldw * 2u;      // row pitch in bytes
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+    const int sub = lane >> 3;
+    const int keyW = PERM ? (((wave & 3) << 1) | ((sub >> 1) & 1)) : sub;
+    const int voffA = (int)((unsigned)(wave * 8 + sub) * rbA) + (((lane & 7) ^ sub) << 4);
+    const int voffW = (int)((unsigned)(wave * 8 + sub) * rbW) + (((lane & 7) ^ keyW) << 4);
+    auto stage_A = [&](int m0, int t, char* st) {
+        const unsigned base = (unsigned)m0 * rbA + (unsigned)(t * PBK * 2);
+        stage_half(rsA, voffA, rbA, base, st, wave);
+        stage_half(rsA, voffA, rbA, base + 128u * rbA, st + PHALF, wave);
+    };
+    auto stage_W = [&](int n0, int t, char* st) {
+        const unsigned base = (unsigned)n0 * rbW + (unsigned)(t * PBK * 2);
+        stage_half(rsW, voffW, rbW, base, st + 2 * PHALF, wave);
+        stage_half(rsW, voffW, rbW, base + 128u * rbW, st + 3 * PHALF, wave);
+    };
+
+    int v = blockIdx.x, tm, tn;
+    tile_of(v, total, tiles_m, tiles_n, tm, tn);
+    int m0 = tm * PBM, n0 = tn * PBM;
+    stage_A(m0, 0, smem);
+    stage_W(n0, 0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // shift wave row 1 by one interval
+
+    // byte offsets of this lane's fragment rows inside a stage
+    const int a_row = wm * PHALF + frow * 128;                                   // + (mh*4+i)*2048
+    const int ca0 = ((0 * 4 + fq) ^ (lane & 7)) << 4, ca1 = ((1 * 4 + fq) ^ (lane & 7)) << 4;
+    // W fragment row of n-tile j for this lane (local to the wave's 64-row strip)
+    //   PERM:   32*(j>>1) + (frow>>2)*8 + (frow&3) + 4*(j&1)      key = (frow>>2)*2 + ((frow>>1)&1)  (same for all j)
+    //   SWIGLU: 16*j + frow                                          key = frow & 7
+    const int wkey = PERM ? (((frow >> 2) << 1) | ((frow >> 1) & 1)) : (frow & 7);
+    const int b_row = (2 + (wn >> 1)) * PHALF +
+                      ((wn & 1) * 64 + (PERM ? ((frow >> 2) * 8 + (frow & 3)) : frow)) * 128;
+    const int cb0 = ((0 * 4 + fq) ^ wkey) << 4, cb1 = ((1 * 4 + fq) ^ wkey) << 4;
+    constexpr int BJ0 = PERM ? 4 * 128 : 16 * 128;      // byte step from n-tile 2q to 2q+1
+    constexpr int BJ1 = 32 * 128;                       // byte step from n-tile pair q to q+1
+
+#define READ_A(st, mh)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        af[i][0] = *reinterpret_cast<const bf16x8*>((st) + a_row + ((mh) * 4 + i) * 2048 + ca0);          \
+        af[i][1] = *reinterpret_cast<const bf16x8*>((st) + a_row + ((mh) * 4 + i) * 2048 + ca1);          \
+    }
+#define READ_B(st, nh)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+        bq[j][0] = *reinterpret_cast<const bf16x8*>((st) + b_row + (nh) * BJ1 + j * BJ0 + cb0);           \
+        bq[j][1] = *reinterpret_cast<const bf16x8*>((st) + b_row + (nh) * BJ1 + j * BJ0 + cb1);           \
+    }
+#define MMA(mh, nh)                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+                acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
+                    bq[j][kk], af[i][kk], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);                      \
+    __builtin_amdgcn_s_setprio(0);
+#define BAR_THEN_WAIT_LDS()                                  \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_barrier();                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);
+#define BAR()                                                \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_barrier();                            \
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm * 128 + i * 16 + frow;
+            if (m < p.M) {
+                if (EPI == GAR_EPI_SWIGLU) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int nin = n0 + wn * 64 + jj * 32;
+                        if (nin < p.N) {
+                            float o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
+                            epilogue_store<bf16_t, EPI>(p, m, (nin >> 1) + fq * 4, o);
+                        }
+                    }
+                } else if (!PERM) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                        if (n < p.N) {
+                            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                            epilogue_store<bf16_t, EPI>(p, m, n, o);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        const int n = n0 + wn * 64 + jq * 32 + fq * 8;
+                        if (n < p.N) {
+                            float o[8] = {acc[i][2 * jq][0], acc[i][2 * jq][1], acc[i][2 * jq][2], acc[i][2 * jq][3],
+                                          acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2],
+                                          acc[i][2 * jq + 1][3]};
+                            epilogue_store8<bf16_t, EPI>(p, m, n, o);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    int sidx = 0;
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < total;
+        int m0n = 0, n0n = 0;
+        if (has_next) {
+            int tmn, tnn;
+            tile_of(vn, total, tiles_m, tiles_n, tmn, tnn);
+            m0n = tmn * PBM;
+            n0n = tnn * PBM;
+        }
+#pragma nounroll
+        for (int t = 0; t < nt; ++t) {
+            char* st = smem + sidx * PSTAGE;
+            char* nx = smem + (sidx ^ 1) * PSTAGE;
+            const bool last = t + 1 == nt;
+            const bool pf = !last || has_next;           // something to prefetch into the other stage
+            const int pm = last ? m0n : m0, pn = last ? n0n : n0, pt = last ? 0 : t + 1;
+            // ---- phase 0
+            READ_A(st, 0)
+            READ_B(st, 0)
+            if (pf) stage_A(pm, pt, nx);
+            BAR_THEN_WAIT_LDS()
+            MMA(0, 0)
+            BAR()
+            // ---- phase 1
+            READ_B(st, 1)
+            if (pf) stage_W(pn, pt, nx);
+            BAR_THEN_WAIT_LDS()
+            MMA(0, 1)
+            BAR()
+            // ---- phase 2
+            READ_A(st, 1)
+            BAR_THEN_WAIT_LDS()
+            MMA(1, 1)
+            BAR()
+            // ---- phase 3
+            READ_B(st, 0)
+            if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 1: before the barrier both rows share
+            BAR_THEN_WAIT_LDS()
+            MMA(1, 0)
+            if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 0: same physical barrier
+            BAR()
+            sidx ^= 1;
+        }
+        // un-stagger (row 0 waits one interval for row 1), run the epilogue of (m0, n0) on both rows at the same time
+        // — the next tile's first K tile is already in LDS, the stores drain under its main loop — then re-stagger.
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+        epilogue();
+        if (!has_next) break;
+        v = vn;
+        m0 = m0n;
+        n0 = n0n;
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+    }
+#undef READ_A
+#undef READ_B
+#undef MMA
+#undef BAR
+#undef BAR_THEN_WAIT_LDS
+}
+
+template <int EPI>
+static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE);
+        attr_set = true;
+    }
+    static const int perm = [] { const char* e = getenv("GAR_GEMM_PERM"); return e ? atoi(e) : 1; }();
+    static const int persist = [] { const char* e = getenv("GAR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+    const int grid = persist ? min(pm * pn, num_cus) : pm * pn;
+    if (perm) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, false>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
+}
+
+// returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel
+bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
+    static const int pp_mode = [] { const char* e = getenv("GAR_GEMM_PP"); return e ? atoi(e) : 1; }();
+    static const int num_cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
+    if (!pp_mode || pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
+    // buffer descriptors address each operand with 32-bit byte offsets
+    if (((int64_t)(p.M - 1) * p.lda + p.K) * 2 >= (int64_t)1 << 31 || ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 >= (int64_t)1 << 31)
+        return false;
+    switch (p.epilogue) {
+        case GAR_EPI_NONE: launch_pp<GAR_EPI_NONE>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_BIAS: launch_pp<GAR_EPI_BIAS>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_BIAS_GELU: launch_pp<GAR_EPI_BIAS_GELU>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_BIAS_SCALE_RES: launch_pp<GAR_EPI_BIAS_SCALE_RES>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_RES: launch_pp<GAR_EPI_RES>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_SWIGLU: launch_pp<GAR_EPI_SWIGLU>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_PATCH_POS: launch_pp<GAR_EPI_PATCH_POS>(p, pm, pn, num_cus, s); break;
+        default: return false;
+    }
+    return true;
+}

@@ -59,6 +59,33 @@ def test_gemm_plain_and_tails(dev, dt, M, N, K):
     assert float((out[:, N:].float() - 7.0).abs().max()) == 0 if ldc > N else True
 
 
+@pytest.mark.parametrize("M,N,K", [(4099, 2048, 192), (8192, 1024, 64), (2049, 4096, 1024), (5000, 1968, 128)])
+def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
+    """shapes large enough (>= 128 tiles of 256x256) to take the ping-pong kernel, incl. M / N tails and every
+    epilogue; compared element-wise with an fp64 reference of the same bf16 inputs."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    a, w = q(rnd(M, K, seed=50), dt), q(rnd(N, K, seed=51, scale=K ** -0.5), dt)
+    A, W_ = a.to(dev, dt), w.to(dev, dt)
+    acc = (a.to(dev).double() @ w.to(dev).double().T).cpu()
+    out = torch.full((M, N), 9.0, dtype=dt, device=dev)
+    ops.gemm(A, W_, out)
+    close(out, acc, dt)
+    bias, gamma, res = q(rnd(N, seed=52), dt), q(rnd(N, seed=53), dt), q(rnd(M, N, seed=54), dt)
+    ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=bias.to(dev, dt))
+    close(out, F.gelu(acc + bias.double()), dt)
+    r = res.to(dev, dt).clone()
+    ops.gemm(A, W_, r, hip.EPI_BIAS_SCALE_RES, bias=bias.to(dev, dt), residual=r, gamma=gamma.to(dev, dt))
+    close(r, res.double() + gamma.double() * (acc + bias.double()), dt)
+    if N % 32 == 0:
+        Fd = N // 2
+        g_w, u_w = w[:Fd], w[Fd:]
+        gu = torch.stack([g_w.view(Fd // 16, 16, K), u_w.view(Fd // 16, 16, K)], 1).reshape(N, K)
+        o2 = torch.empty(M, Fd, dtype=dt, device=dev)
+        ops.gemm(A, gu.to(dev, dt), o2, hip.EPI_SWIGLU)
+        close(o2, F.silu(acc[:, :Fd]) * acc[:, Fd:], dt)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [4, 200])
 def test_gemm_epilogues(dev, dt, M):

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the bf16 GEMM kernels on the benchmark's shapes (random data, HIP-event timing).
+GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grasp-any-region_amd"))
+import torch  # noqa: E402
+
+from gar_amd import hip, ops  # noqa: E402
+
+SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 1024, 1024, hip.EPI_BIAS_SCALE_RES),
+          ("vit fc1", 139400, 4096, 1024, hip.EPI_BIAS_GELU), ("vit fc2", 139400, 1024, 4096, hip.EPI_BIAS_SCALE_RES),
+          ("llm qkv", 37744, 3072, 2048, hip.EPI_NONE), ("llm o", 37744, 2048, 2048, hip.EPI_RES),
+          ("llm gate/up", 37744, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 37744, 2048, 8192, hip.EPI_RES),
+          ("square 8k", 8192, 8192, 8192, hip.EPI_NONE)]
+
+
+def main():
+    hip.require_device(0)
+    dev = "cuda:0"
+    reps = int(os.environ.get("REPS", "5"))
+    tot_f = tot_t = 0.0
+    for name, M, N, K, epi in SHAPES:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+        out = torch.empty(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
+        kw = {}
+        if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES):
+            kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
+        if epi in (hip.EPI_BIAS_SCALE_RES, hip.EPI_RES):
+            kw["residual"] = out
+        if epi == hip.EPI_BIAS_SCALE_RES:
+            kw["gamma"] = torch.randn(N, device=dev).to(torch.bfloat16)
+        for _ in range(2):
+            ops.gemm(a, w, out, epi, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.gemm(a, w, out, epi, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * M * N * K
+        tot_f += fl
+        tot_t += ms
+        print(f"{name:12s} M={M:6d} N={N:5d} K={K:4d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    print(f"weighted: {tot_f / tot_t / 1e9:.1f} TFLOP/s  (GAR_GEMM_PP={os.environ.get('GAR_GEMM_PP', '1')})")
+
+
+if __name__ == "__main__":
+    main()
