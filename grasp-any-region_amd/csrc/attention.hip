@@ -16,6 +16,10 @@
 // f32 variant (parity mode): same structure on v_mfma_f32_32x32x2_f32 (exact f32 fma chains), padded LDS tiles.
 #include "common.h"
 
+// attention_bf16.hip: DMA-staged bf16 kernel (default for bf16); false -> use the register-staged kernel below
+bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
+                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s);
+
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 
@@ -27,6 +31,8 @@ __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
 
 // swizzle key of a row for a tile whose rows are RS bytes: makes 16 rows read at one logical chunk hit 16 distinct
 // 16-byte slots of the 256-byte LDS bank row ("attention LDS image").
+#define RESCALE_THR 6.0f   // log2 domain
+
 template <int RS> __device__ __forceinline__ int swz_key(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
 
 template <int HD, bool CAUSAL>
@@ -41,7 +47,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     constexpr int NDB = HD / 32;                // O^T row blocks
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | Vt]
     const int kv_len = kv_len_dev ? kv_len_dev[0] : kv_len_arg;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: tile-skip / mask branches stay uniform
     const int l31 = lane & 31, h = lane >> 5;
     const int qb = gridDim.x - 1 - blockIdx.x;  // heavy (late) causal blocks first
     const int head = blockIdx.y, b = blockIdx.z;
@@ -158,17 +165,27 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_use);        // m_run = -inf -> 0
-            m_run = m_new;
+            // deferred rescale: keep the old reference max while no row's max grew by more than 2^RESCALE_THR
+            // (P <= 2^THR is harmless in bf16/f32); the O / l rescale then runs only on the few tiles where it matters.
+            if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
+                const float m_new = fmaxf(m_run, mx);
+                const float m_nu = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);      // m_run = -inf -> 0
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            const float m_use = m_run == -INFINITY ? 0.f : m_run;
             float ps = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 float p[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[blk][r] - m_use); ps += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     u32x4 w;
@@ -179,11 +196,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
                     pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
                 }
             }
-            l_run = l_run * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            l_run += ps;
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
                 const int row = d * 32 + l31;
@@ -384,6 +397,11 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
                   "attention: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
     GAR_CHECK_ARG(hd == 64 || hd == 128, "attention: head_dim %d not built (64, 128)", hd);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16 &&
+        gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s)) {
+        GAR_CHECK_LAUNCH();
+        return GAR_OK;
+    }
     if (hd == 64) launch_attn<64>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s);
     else launch_attn<128>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s);
     GAR_CHECK_LAUNCH();
@@ -472,7 +490,7 @@ __global__ __launch_bounds__(64) void decode_attn_bf16_kernel(const bf16_t* __re
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         m_run = m_new;
         float ps = 0.f;
         bf16x8 pf[2][2];
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(64) void decode_attn_bf16_kernel(const bf16_t* __re
         for (int blk = 0; blk < 2; ++blk) {
             float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = exp2f(s[blk][r] - m_use); ps += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 u32x4 w;
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(64) void decode_combine_kernel(const float* __restr
     for (int i = 0; i < HD / 64; ++i) acc[i] = 0.f;
     for (int s = 0; s < nsplit; ++s) {
         const float* p = base + s * sstride;
-        const float w = exp2f(p[HD] - m_use);       // exp2(-inf) = 0 for empty splits
+        const float w = __builtin_amdgcn_exp2f(p[HD] - m_use);       // exp2(-inf) = 0 for empty splits
         l += w * p[HD + 1];
 #pragma unroll
         for (int i = 0; i < HD / 64; ++i) acc[i] += w * p[i * 64 + lane];

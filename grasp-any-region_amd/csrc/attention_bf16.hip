@@ -1,0 +1,231 @@
+// bf16 flash attention, v2 (prefill / ViT): same lane-local S^T -> softmax -> P -> O^T scheme as attention.hip, with
+//   * K / Vt tiles DMA'd HBM -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass; the XOR
+//     swizzle is applied to the per-lane SOURCE offset; rows past the end of the kv slab are zero-filled by the buffer
+//     descriptor), double-buffered, the next tile in flight during the whole compute of the current one;
+//   * raw v_exp_f32, first MFMA of every accumulator chain fed with an inline-zero C operand;
+//   * deferred rescale: O / l are rescaled only when some row's running max grew by more than 2^RESCALE_THR.
+#include <stdlib.h>
+
+#include "common.h"
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define RESCALE_THR 6.0f   // log2 domain
+
+typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+typedef float f32v2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) {
+    f32v2_t v = {lo, hi};
+    bf16v2_t r = __builtin_convertvector(v, bf16v2_t);
+    return __builtin_bit_cast(unsigned int, r);
+}
+
+template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                              int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
+                                                              int kv_stride, const int32_t* __restrict__ kv_len_dev) {
+    constexpr int KRS = HD * 2;                 // K tile row bytes
+    constexpr int KT = 64 * KRS;                // K tile bytes   [64 kv][HD]
+    constexpr int VT = HD * 128;                // Vt tile bytes  [HD][64 kv]
+    constexpr int NKD = HD / 16;                // QK^T k-steps
+    constexpr int NDB = HD / 32;                // O^T row blocks
+    constexpr int KI = KT / 4096;               // K DMA instructions per wave per tile (1 KiB each)
+    constexpr int VI = VT / 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | Vt]
+    const int kv_len = kv_len_dev ? kv_len_dev[0] : kv_len_arg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int qb = gridDim.x - 1 - blockIdx.x;  // heavy (late) causal blocks first
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int kvh = head / (Hq / Hkv);
+    const int q0 = qb * 128 + wave * 32;        // this wave's first query
+    const int coff = kv_len - q_len;            // causal: kv <= q + coff
+    const bf16_t* Qp = Q + (((int64_t)b * Hq + head) * q_pad) * HD;
+    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const unsigned slab = (unsigned)kv_stride * HD * 2u;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
+
+    // per-lane source offsets of DMA piece 0 (piece i adds a scalar): LDS image is lane-linear, 1 KiB per piece
+    int voffK, voffV;
+    if (HD == 64) {          // piece = 8 rows x 128 B
+        const int row = wave * 8 + (lane >> 3);
+        voffK = row * 128 + (((lane & 7) ^ key_of<128>(row)) << 4);
+    } else {                 // piece = 4 rows x 256 B
+        const int row = wave * 4 + (lane >> 4);
+        voffK = row * 256 + (((lane & 15) ^ key_of<256>(row)) << 4);
+    }
+    {
+        const int row = wave * 8 + (lane >> 3);      // Vt piece = 8 d-rows x 128 B (64 kv)
+        voffV = (int)((unsigned)row * (unsigned)kv_stride * 2u) + (((lane & 7) ^ key_of<128>(row)) << 4);
+    }
+    auto stage = [&](int t, int buf) {
+        char* ks = smem + buf * (KT + VT);
+        char* vs = ks + KT;
+        const unsigned kbase = (unsigned)t * 64u * KRS;                 // 64 kv rows per tile
+        const unsigned vbase = (unsigned)t * 128u;                      // 64 kv columns
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
+                                                     voffK + (int)(kbase + (unsigned)i * 4096u), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < VI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
+                                                     voffV + (int)(vbase + (unsigned)i * 32u * (unsigned)kv_stride * 2u),
+                                                     0, 0, 0);
+    };
+
+    // Q fragments (B operand): Q[q0 + l31][16 kd + 8h .. +8]
+    bf16x8 qf[NKD];
+    {
+        const int qrow = min(q0 + l31, q_pad - 1);
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+            qf[kd] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * HD + kd * 16 + h * 8);
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kv_end = kv_len;
+    if (CAUSAL) kv_end = min(kv_len, qb * 128 + 127 + coff + 1);
+    const int ntiles = (kv_end + 63) / 64;
+    if (ntiles > 0) stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2<->3 swapped
+    const bool wave_active = q0 < q_len;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // LDS byte offsets of this lane's fragment rows
+    int koff[2], kkey[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int row = blk * 32 + prow;
+        koff[blk] = row * KRS;
+        kkey[blk] = key_of<KRS>(row);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        const int kv0 = t * 64;
+        const bool skip = !wave_active || (CAUSAL && kv0 > q0 + 31 + coff);     // wave-uniform
+        if (!skip) {
+            const char* ks = smem + buf * (KT + VT);
+            const char* vs = ks + KT;
+            f32x16 s[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int kd = 0; kd < NKD; ++kd) {
+                    const bf16x8 kf =
+                        *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+                }
+            }
+            // register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
+            const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
+            if (need_mask) {
+                const int qi = q0 + l31;
+                const int lim = CAUSAL ? min(kv_len - 1, qi + coff) : kv_len - 1;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
+                        s[blk][r] = kv <= lim ? s[blk][r] : -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
+                const float m_new = fmaxf(m_run, mx);
+                const float m_nu = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            const float m_use = m_run == -INFINITY ? 0.f : m_run;
+            float ps = 0.f;
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    u32x4 w;
+                    w[0] = cvt_pk(p[tt * 8 + 0], p[tt * 8 + 1]);
+                    w[1] = cvt_pk(p[tt * 8 + 2], p[tt * 8 + 3]);
+                    w[2] = cvt_pk(p[tt * 8 + 4], p[tt * 8 + 5]);
+                    w[3] = cvt_pk(p[tt * 8 + 6], p[tt * 8 + 7]);
+                    pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
+            l_run += ps;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                const int row = d * 32 + l31;
+                const int key = key_of<128>(row);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int c = (blk * 2 + tt) * 2 + h;
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + ((c ^ key) << 4));
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[blk][tt], o[d], 0, 0, 0);
+                    }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: O[b*q_len + q][head*HD + d], d = 32 db + (r&3) + 8 (r>>2) + 4 h
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const int qi = q0 + l31;
+    if (qi < q_len) {
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        bf16_t* op = O + ((int64_t)b * q_len + qi) * ((int64_t)Hq * HD) + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv, o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv};
+                st4(op + d * 32 + g * 8 + h * 4, v);
+            }
+    }
+}
+
+// returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip)
+bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
+                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s) {
+    static const int mode = [] { const char* e = getenv("GAR_ATTN_V2"); return e ? atoi(e) : 1; }();
+    if (!mode) return false;
+    if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
+    dim3 grid((q_len + 127) / 128, Hq, B), block(256);
+    const int lds = 2 * (64 * hd * 2 + hd * 128);
+#define LAUNCH_V2(HD_, C_)                                                                                            \
+    hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,       \
+                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev)
+    if (hd == 64) { if (causal) LAUNCH_V2(64, true); else LAUNCH_V2(64, false); }
+    else if (hd == 128) { if (causal) LAUNCH_V2(128, true); else LAUNCH_V2(128, false); }
+    else return false;
+#undef LAUNCH_V2
+    return true;
+}
