@@ -1,0 +1,241 @@
+// Decode attention (q_len = 1): split-KV, GQA-aware, HBM-bound.
+//
+//   Block = 4 waves = one (split, kv head, batch). The G = Hq/Hkv query heads sharing a kv head are the columns of
+//   the MFMA B operand (columns >= G are zero), so K and Vt of that kv head stream from HBM exactly ONCE per step.
+//   The block's kv range is cut in 64-kv tiles dealt round-robin to its waves; each wave loads its K / Vt MFMA
+//   fragments straight from global memory into VGPRs (no reuse across waves -> no LDS round trip), one tile AHEAD of
+//   the tile it is computing (register double buffering), keeps an online softmax, and the four waves are merged in
+//   LDS into one un-normalised partial (m, l, O[G][HD]) per block. decode_combine_kernel merges the splits.
+//   kv length comes from device memory so the captured hipGraph replays unchanged for every token.
+//   Algorithmic bytes per launch: B * Hkv * kv_len * HD * 2 (K and Vt) * sizeof(bf16).
+#include "common.h"
+
+typedef __bf16 bf16v2_d __attribute__((ext_vector_type(2)));
+typedef float f32v2_d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cvt_pk_d(float lo, float hi) {
+    f32v2_d v = {lo, hi};
+    bf16v2_d r = __builtin_convertvector(v, bf16v2_d);
+    return __builtin_bit_cast(unsigned int, r);
+}
+
+template <int HD>
+struct Frags {
+    bf16x8 k[2][HD / 16];
+    bf16x8 v[HD / 32][4];
+};
+
+template <int HD>
+__device__ __forceinline__ void load_frags(Frags<HD>& f, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp,
+                                           int kv0, int kv_stride, int prow, int l31, int h) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int row = min(kv0 + blk * 32 + prow, kv_stride - 1);
+#pragma unroll
+        for (int kd = 0; kd < HD / 16; ++kd)
+            f.k[blk][kd] = __builtin_nontemporal_load(
+                reinterpret_cast<const bf16x8*>(Kp + (int64_t)row * HD + kd * 16 + h * 8));
+    }
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            f.v[d][c] = __builtin_nontemporal_load(
+                reinterpret_cast<const bf16x8*>(Vp + (int64_t)(d * 32 + l31) * kv_stride + kv0 + c * 16 + h * 8));
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ Vt, float* __restrict__ part,
+                                                               int Hq, int Hkv, int kv_stride,
+                                                               const int32_t* __restrict__ kv_len_dev) {
+    constexpr int NKD = HD / 16, NDB = HD / 32;
+    __shared__ float red[4][8][HD + 2];           // per wave: O[g][d], m, l   (g < G <= 8)
+    const int kv_len = kv_len_dev[0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int G = Hq / Hkv;
+    const int ntiles = (kv_len + 63) / 64;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    bf16x8 qf[NKD];
+    {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+            qf[kd] = l31 < G ? *reinterpret_cast<const bf16x8*>(qp + kd * 16 + h * 8) : z;
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const Frags<HD>& f, int tt_) {
+        const int kv0 = tt_ * 64;
+        f32x16 s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int kd = 0; kd < NKD; ++kd)
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+        if (kv0 + 64 > kv_len) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
+                    s[blk][r] = kv < kv_len ? s[blk][r] : -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float ps = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                u32x4 w;
+                w[0] = cvt_pk_d(p[tt * 8 + 0], p[tt * 8 + 1]);
+                w[1] = cvt_pk_d(p[tt * 8 + 2], p[tt * 8 + 3]);
+                w[2] = cvt_pk_d(p[tt * 8 + 4], p[tt * 8 + 5]);
+                w[3] = cvt_pk_d(p[tt * 8 + 6], p[tt * 8 + 7]);
+                pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
+        }
+    };
+    // register double buffering: fragments of the wave's NEXT tile are in flight while the current one is computed
+    Frags<HD> fa, fb;
+    int t = t0 + wave;
+    if (t < t1) load_frags<HD>(fa, Kp, Vp, t * 64, kv_stride, prow, l31, h);
+    for (; t < t1; t += 8) {
+        const bool has_b = t + 4 < t1;
+        if (has_b) load_frags<HD>(fb, Kp, Vp, (t + 4) * 64, kv_stride, prow, l31, h);
+        compute(fa, t);
+        if (has_b) {
+            if (t + 8 < t1) load_frags<HD>(fa, Kp, Vp, (t + 8) * 64, kv_stride, prow, l31, h);
+            compute(fb, t + 4);
+        }
+    }
+    // ---- merge the four waves (LDS), one partial per block
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (l31 < G) {
+        float* pp = &red[wave][l31][0];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp[d * 32 + g4 * 8 + h * 4 + e] = o[d][g4 * 4 + e];
+        if (h == 0) { pp[HD] = m_run; pp[HD + 1] = l_tot; }
+    }
+    __syncthreads();
+    // thread (g = tid / 64 ... ) : G*HD outputs, 256 threads
+    for (int idx = tid; idx < G * HD; idx += 256) {
+        const int g = idx / HD, d = idx % HD;
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w][g][HD]);
+        const float m_use = m == -INFINITY ? 0.f : m;
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __builtin_amdgcn_exp2f(red[w][g][HD] - m_use);
+            acc += sc * red[w][g][d];
+            l += sc * red[w][g][HD + 1];
+        }
+        float* pp = part + ((((int64_t)b * Hkv + kvh) * nsplit + split) * G + g) * (HD + 2);
+        pp[d] = acc;
+        if (d == 0) { pp[HD] = m; pp[HD + 1] = l; }
+    }
+}
+
+// one wave per (b, q head): lanes over splits for the statistics, then over d for the accumulation
+template <int HD>
+__global__ __launch_bounds__(64) void decode_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ O, int Hq,
+                                                            int Hkv, int nsplit) {
+    const int head = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int G = Hq / Hkv, kvh = head / G, g = head % G;
+    const float* base = part + ((((int64_t)b * Hkv + kvh) * nsplit) * G + g) * (HD + 2);
+    const int64_t sstride = (int64_t)G * (HD + 2);
+    const float ms = lane < nsplit ? base[lane * sstride + HD] : -INFINITY;
+    const float ls = lane < nsplit ? base[lane * sstride + HD + 1] : 0.f;
+    const float m = wave_max(ms);
+    const float m_use = m == -INFINITY ? 0.f : m;
+    const float wgt = __builtin_amdgcn_exp2f(ms - m_use);          // 0 for empty splits / lanes >= nsplit
+    const float l = wave_sum(wgt * ls);
+    float acc[HD / 64];
+#pragma unroll
+    for (int i = 0; i < HD / 64; ++i) acc[i] = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __shfl(wgt, s, 64);
+#pragma unroll
+        for (int i = 0; i < HD / 64; ++i) acc[i] += w * base[s * sstride + i * 64 + lane];
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int i = 0; i < HD / 64; ++i) O[((int64_t)b * Hq + head) * HD + i * 64 + lane] = f2bf(acc[i] * inv);
+}
+
+extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits) {
+    return (int64_t)B * Hq * max_splits * (hd + 2) * 4;
+}
+
+extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq,
+                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, int max_splits, void* workspace,
+                                    gar_stream_t stream) {
+    GAR_CHECK_ARG(q && Kc && Vtc && O && kv_len_dev, "attention_decode: null pointer");
+    GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
+    GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
+    GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
+    if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
+        return gar_attention(dtype, q, Kc, Vtc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, stream);
+    GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
+    GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(max_splits, Hkv, B);
+    if (hd == 64) {
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev);
+        hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace, (bf16_t*)O, Hq,
+                           Hkv, max_splits);
+    } else {
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev);
+        hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace, (bf16_t*)O,
+                           Hq, Hkv, max_splits);
+    }
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}

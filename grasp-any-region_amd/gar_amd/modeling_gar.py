@@ -359,8 +359,8 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
-        # enough (split, kv head, batch) waves to cover the chip: ~2048 single-wave blocks
-        nsplit = max(1, min(64, 2048 // max(1, B * Hkv)))
+        # enough (split, kv head, batch) 4-wave blocks to cover the chip: ~512 blocks = 2048 waves
+        nsplit = max(1, min(64, 512 // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
         fuse = B <= 16                      # RMSNorm folded into the skinny GEMM prologue (no separate launch)
