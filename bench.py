@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GAR_BENCH_BATCH", "8")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GAR_BENCH_BATCH", "16")),
                     help="regions per step per GPU (continuous batching of independent regions)")
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--max-num-tiles", type=int, default=16)

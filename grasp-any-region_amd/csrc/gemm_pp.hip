@@ -42,6 +42,7 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff
 template <int EPI, bool PERMT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
     constexpr bool PERM = PERMT && EPI != GAR_EPI_SWIGLU;
+    constexpr bool LDS_EPI = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
     const int total = tiles_m * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,6 +127,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     __builtin_amdgcn_sched_barrier(0);
 
     auto epilogue = [&]() {
+        if (p.tokens_out == -12345) {       // DEBUG (tools/bench_gemm.py only): skip the epilogue, keep acc live
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm * 128 + i * 16 + frow;
@@ -163,6 +171,94 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                     }
                 }
             }
+        }
+    };
+
+    // Row-coalesced epilogue through LDS (PERM epilogues): the just-consumed stage (64 KiB) holds 64 output rows x 256
+    // columns of fp32 accumulators at a time; the owning wave row writes its fragments (ds_write_b128, XOR-swizzled
+    // 16-byte chunks), then ALL eight waves read whole rows back and run bias / LayerScale / residual / store on
+    // 8-column groups: every global access of a wave instruction is 2 rows x 512 contiguous bytes.
+    // Called with both wave rows aligned; 2 barriers per 64-row chunk.
+    auto epilogue_lds = [&](char* E) {
+        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES;
+        constexpr bool HAS_RES = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES;
+        // a thread always serves the same 8-column group (cg = tid & 31): bias / LayerScale are loaded once per tile
+        const int cg = tid & 31, r0 = tid >> 5;
+        const int n = n0 + cg * 8;
+        const bool nok = n < p.N;
+        float bias8[8], gam8[8];
+        if (HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
+        if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // issue this chunk's row-dependent loads (residual / pos-embed) before waiting for the LDS hand-over
+            uint4 aux[4];
+            int64_t off[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + c * 64 + k * 16 + r0;
+                ok[k] = nok && m < p.M;
+                if (EPI == GAR_EPI_PATCH_POS) {
+                    const int tile = m / p.tokens_in;
+                    const int tok = p.token_offset + (m - tile * p.tokens_in);
+                    off[k] = ((int64_t)tile * p.tokens_out + tok) * p.ldc + n;
+                    if (ok[k]) aux[k] = *reinterpret_cast<const uint4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + n);
+                } else {
+                    off[k] = (int64_t)m * p.ldc + n;
+                    if (p.tokens_out == -12346) off[k] = (int64_t)(m - m0) * p.ldc + (n - n0);   // DEBUG: L2-resident stores
+                    if (HAS_RES && ok[k])
+                        aux[k] = *reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + n);
+                }
+            }
+            if (wm == (c >> 1)) {
+#pragma unroll
+                for (int il = 0; il < 4; ++il) {
+                    const int i = (c & 1) * 4 + il;
+                    const int row = il * 16 + frow;
+                    char* rp = E + row * 1024;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int chunk = wn * 16 + (j >> 1) * 8 + fq * 2 + (j & 1);
+                        *reinterpret_cast<f32x4*>(rp + ((chunk ^ (frow & 7)) << 4)) = acc[i][j];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = k * 16 + r0;
+                const char* rp = E + row * 1024;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rp + (((cg * 2) ^ (row & 7)) << 4));
+                const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((cg * 2 + 1) ^ (row & 7)) << 4));
+                if (ok[k]) {
+                    float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    if (HAS_BIAS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += bias8[e];
+                    }
+                    if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
+                    }
+                    if (HAS_RES || EPI == GAR_EPI_PATCH_POS) {
+                        const unsigned int w[4] = {aux[k].x, aux[k].y, aux[k].z, aux[k].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                            if (EPI == GAR_EPI_BIAS_SCALE_RES) {
+                                o[2 * e] = lo + gam8[2 * e] * o[2 * e];
+                                o[2 * e + 1] = hi + gam8[2 * e + 1] * o[2 * e + 1];
+                            } else {
+                                o[2 * e] += lo;
+                                o[2 * e + 1] += hi;
+                            }
+                        }
+                    }
+                    st8((bf16_t*)p.C + off[k], o);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
         }
     };
 
@@ -218,7 +314,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // un-stagger (row 0 waits one interval for row 1), run the epilogue of (m0, n0) on both rows at the same time
         // — the next tile's first K tile is already in LDS, the stores drain under its main loop — then re-stagger.
         if (wm == 0) __builtin_amdgcn_s_barrier();
-        epilogue();
+        if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+        else epilogue();
         if (!has_next) break;
         v = vn;
         m0 = m0n;
@@ -259,6 +356,11 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
     }();
     const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
     if (!pp_mode || pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
+    // the row-coalesced epilogue moves 16-byte vectors of C / residual / bias / gamma / pos
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if ((p.ldc % 8) != 0 || !al16(p.C) || (p.bias && !al16(p.bias)) || (p.gamma && !al16(p.gamma)) ||
+        (p.residual && (!al16(p.residual) || (p.ldr % 8) != 0)) || (p.pos && !al16(p.pos)))
+        return false;
     // buffer descriptors address each operand with 32-bit byte offsets
     if (((int64_t)(p.M - 1) * p.lda + p.K) * 2 >= (int64_t)1 << 31 || ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 >= (int64_t)1 << 31)
         return false;

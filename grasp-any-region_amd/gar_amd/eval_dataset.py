@@ -158,3 +158,57 @@ class MultiRegionDataset(_Base):
     def __getitem__(self, index):
         d = self._parse_annotations()
         return self._finish(d, d["prompt"])
+
+
+class VideoRegionCaptionDataset:
+    """Sample builder for the video replay path (A13, modeling_perception_lm.py:765-852). The reference ships no caller
+    for that path; this builder follows its contract: F frames, each resized to ONE tile (no
+    thumbnail), one binary mask per frame drawn with ``prompt_token``'s id, frame f's 256 placeholders are
+    ``<|reserved_special_token_{2+f}|>`` and its bbox is keyed by that token's id. The returned dict adds
+    ``feature_replay_video=True`` and ``video_frame_tokens`` for ``GARModel.generate``."""
+
+    def __init__(self, frames, masks, processor, prompt_token="<Prompt1>", data_dtype=torch.bfloat16, device=None,
+                 question="Describe this masked region in the video in detail.", **kwargs):
+        assert len(frames) == len(masks) and 1 <= len(frames) <= 8
+        self.frames, self.masks, self.processor = frames, masks, processor
+        self.prompt_token, self.question = prompt_token, question
+        self.data_dtype = data_dtype
+        self.device = device or _default_device()
+        base = getattr(processor.tokenizer, "prompt_base", 128256)
+        tk = processor.tokenizer
+        self.prompt_id = tk.convert_tokens_to_ids(prompt_token) - base
+        self.no_prompt_id = tk.convert_tokens_to_ids("<NO_Prompt>") - base
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, index):
+        tk, ip = self.processor.tokenizer, self.processor.image_processor
+        rep = self.processor.num_image_tokens(1)
+        pix, msk, bboxes, frame_tokens = [], [], {}, []
+        body = ""
+        for f, (frame, mask) in enumerate(zip(self.frames, self.masks)):
+            mask_np = np.asarray(mask).astype(bool)
+            filled = np.full((frame.height, frame.width), self.no_prompt_id, dtype=np.int32)
+            filled[mask_np] = self.prompt_id
+            nz = np.argwhere(mask_np)
+            (y_min, x_min), (y_max, x_max) = nz.min(axis=0), nz.max(axis=0)
+            tok = f"<|reserved_special_token_{f + 2}|>"
+            tid = tk.convert_tokens_to_ids(tok)
+            frame_tokens.append(tid)
+            bboxes[str(tid)] = (x_min / frame.width, y_min / frame.height, x_max / frame.width, y_max / frame.height)
+            pix.append(ip.single_tile(frame, "bicubic"))
+            msk.append(ip.single_tile(Image.fromarray(filled), "nearest"))
+            body += f"Frame {f}: " + tok * rep + "\n"
+        qs = (f"There are some objects I am curious about: {self.prompt_token};\n" + body + self.question)
+        prompt = ("<|begin_of_text|><|start_header_id|>user<|end_header_id|>\n\n" + tk.image_token * (rep * len(pix)) + qs +
+                  "<|eot_id|><|start_header_id|>assistant<|end_header_id|>\n\n")
+        enc = tk([prompt])
+        dev = self.device
+        ids = torch.tensor(enc["input_ids"], dtype=torch.int64)
+        return dict(input_ids=ids.to(dev),
+                    attention_mask=torch.ones_like(ids).to(dev).to(self.data_dtype),
+                    pixel_values=torch.cat(pix, 0).to(dev).to(self.data_dtype),
+                    global_mask_values=torch.cat(msk, 0).to(dev).to(self.data_dtype),
+                    bboxes=[bboxes], aspect_ratios=torch.tensor([[1, 1]]).to(dev),
+                    feature_replay_video=True, video_frame_tokens=frame_tokens)

@@ -77,6 +77,7 @@ class GARModel:
         self._prepare_weights(weights)
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
+        self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
@@ -245,18 +246,30 @@ class GARModel:
         return feats
 
     # ---- inputs_embeds: embedding + placeholder scatter + RoI replay (A7-A11) -----------------------------------------
-    def build_inputs_embeds(self, input_ids, feats, bboxes, aspect_ratios, tiles_per_sample: int, validate=True):
+    def build_inputs_embeds(self, input_ids, feats, bboxes, aspect_ratios, tiles_per_sample: int, validate=True,
+                            video_frame_tokens: Optional[Sequence[int]] = None):
         cfg = self.config
         B, S = input_ids.shape
         C_l = cfg.mllm_config.text_config.hidden_size
         P = cfg.pooled_side
         key = ("emb", B, S)
         ids = input_ids.to(self.device, torch.int64).contiguous()
+        if video_frame_tokens is not None:
+            # A13 video replay (modeling_perception_lm.py:765-852): one pooled map per frame, crop token per frame
+            crop_ids = [int(t) for t in video_frame_tokens]
+            if len(crop_ids) != tiles_per_sample or len(crop_ids) > 8:
+                raise hip.GarError(f"video replay: {len(crop_ids)} frame tokens for {tiles_per_sample} frames (max 8)")
+            vkey = tuple(crop_ids)
+            if vkey not in self._video_crop_ids:
+                self._video_crop_ids[vkey] = torch.tensor(crop_ids, dtype=torch.int64, device=self.device)
+            crop_ids_dev = self._video_crop_ids[vkey]
+        else:
+            crop_ids, crop_ids_dev = self.crop_tokens_ids, self.crop_ids_dev
         slot = self._buf(key, "slot", (B, S), torch.int32)
         counts = self._buf(key, "counts", (B,), torch.int32)
-        spans = self._buf(key, "spans", (B, len(self.crop_tokens_ids), 2), torch.int32)
+        spans = self._buf(key, "spans", (B, len(crop_ids), 2), torch.int32)
         embeds = self._buf(key, "embeds", (B, S, C_l))
-        ops.placeholder_scan(ids, cfg.mllm_config.image_token_id, self.crop_ids_dev, slot, counts, spans)
+        ops.placeholder_scan(ids, cfg.mllm_config.image_token_id, crop_ids_dev, slot, counts, spans)
         n_rows = tiles_per_sample * P * P
         ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
         if validate:
@@ -266,12 +279,17 @@ class GARModel:
             for b in range(B):
                 if cnt[b] != n_rows:
                     raise ValueError(f"Image features and image tokens do not match: tokens: {cnt[b]}, features {n_rows}")
-        ar = aspect_ratios.tolist() if torch.is_tensor(aspect_ratios) else aspect_ratios
+        video = video_frame_tokens is not None
+        if not video:
+            ar = aspect_ratios.tolist() if torch.is_tensor(aspect_ratios) else aspect_ratios
         for b in range(B):
-            ncw, nch = int(ar[b][0]), int(ar[b][1])
-            assert ncw * nch == tiles_per_sample - 1, f"{ncw * nch} != {tiles_per_sample - 1}"
+            if video:
+                ncw = nch = 1                       # each frame is its own P x P map (feat_h = feat_w = P, :787)
+            else:
+                ncw, nch = int(ar[b][0]), int(ar[b][1])
+                assert ncw * nch == tiles_per_sample - 1, f"{ncw * nch} != {tiles_per_sample - 1}"
             feat_h, feat_w = P * nch, P * ncw
-            for ci, crop_token in enumerate(self.crop_tokens_ids):
+            for ci, crop_token in enumerate(crop_ids):
                 if str(crop_token) not in bboxes[b]:
                     if validate and sp[b][ci][1] >= 0:
                         raise KeyError(str(crop_token))
@@ -286,8 +304,9 @@ class GARModel:
                 orig_h, orig_w = feat_h * cfg.feat_stride, feat_w * cfg.feat_stride
                 ss = feat_w / orig_w
                 roi = (x1 * orig_w * ss, y1 * orig_h * ss, x2 * orig_w * ss, y2 * orig_h * ss)
-                ops.roi_replay(feats[b * tiles_per_sample:(b + 1) * tiles_per_sample], embeds[b], spans[b], ci, 1, ncw,
-                               nch, P, C_l, S, roi, ss, 2, True)
+                # image: map = tiles 1.. (thumbnail dropped, modeling_gar.py:351); video: map = frame ci only
+                ops.roi_replay(feats[b * tiles_per_sample:(b + 1) * tiles_per_sample], embeds[b], spans[b], ci,
+                               ci if video else 1, ncw, nch, P, C_l, S, roi, ss, 2, True)
         return embeds
 
     # ---- Llama (A12) --------------------------------------------------------------------------------------------------
@@ -388,7 +407,8 @@ class GARModel:
     def generate(self, pixel_values=None, global_mask_values=None, aspect_ratios=None, bboxes=None, input_ids=None,
                  attention_mask=None, generation_config=None, output_hidden_states=None, return_dict=None,
                  max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
-                 return_logits: bool = False, sync_every: int = 16, **generate_kwargs) -> GenerateOutput:
+                 return_logits: bool = False, sync_every: int = 16, feature_replay_video: bool = False,
+                 video_frame_tokens: Optional[Sequence[int]] = None, **generate_kwargs) -> GenerateOutput:
         """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428).
 
         B = input_ids.shape[0] samples are processed together (the reference handles B=1 per call; its loop over
@@ -413,7 +433,13 @@ class GARModel:
         if pixel_values is not None:
             tiles = pixel_values.shape[0] // B if pixel_values.dim() == 4 else pixel_values.shape[1]
             feats = self.get_image_features(pixel_values, global_mask_values)
-            embeds = self.build_inputs_embeds(input_ids, feats, bboxes, aspect_ratios, tiles, validate)
+            if feature_replay_video and video_frame_tokens is None:
+                # <|reserved_special_token_{2+f}|> of frame f (modeling_perception_lm.py:777-780): the first
+                # prompt_numbers ids are config.crop_tokens_ids, the following reserved tokens are consecutive ids
+                base = list(self.crop_tokens_ids)
+                video_frame_tokens = (base + [base[-1] + 1 + i for i in range(max(0, tiles - len(base)))])[:tiles]
+            embeds = self.build_inputs_embeds(input_ids, feats, bboxes, aspect_ratios, tiles, validate,
+                                              video_frame_tokens if feature_replay_video else None)
         else:
             ids = input_ids.to(self.device, torch.int64).contiguous()
             embeds = self._buf(("emb", B, S), "embeds", (B, S, cfg.mllm_config.text_config.hidden_size))

@@ -119,6 +119,14 @@ class GARImageProcessor:
         self.image_mean = 0.5
         self.image_std = 0.5
 
+    def single_tile(self, image: Image.Image, resample: Optional[str] = None) -> torch.Tensor:
+        """One frame -> one normalised tile [1,3,ts,ts] (the ``max_num_tiles=1`` branch of ``resize``, :268-286)."""
+        resample = resample or self.resample
+        rgb = np.asarray(image.convert("RGB"), dtype=np.uint8)
+        x = torch.from_numpy(rgb.copy()).permute(2, 0, 1).contiguous()
+        t = _resize_u8(x, (self.tile_size, self.tile_size), resample).to(torch.float32)
+        return ((t / 255.0 - self.image_mean) / self.image_std).unsqueeze(0)
+
     def __call__(self, image: Image.Image, resample: Optional[str] = None):
         resample = resample or self.resample
         rgb = np.asarray(image.convert("RGB"), dtype=np.uint8)
@@ -143,6 +151,8 @@ LLAMA3_SPECIALS = {
     "<|start_header_id|>": 128006, "<|end_header_id|>": 128007,
     "<|reserved_special_token_4|>": 128008, "<|eot_id|>": 128009,
     "<|reserved_special_token_5|>": 128010, "<|reserved_special_token_6|>": 128011,
+    "<|reserved_special_token_7|>": 128012, "<|reserved_special_token_8|>": 128013,
+    "<|reserved_special_token_9|>": 128014,
     "<Prompt0>": 128256, "<Prompt1>": 128257, "<Prompt2>": 128258, "<Prompt3>": 128259,
     "<Prompt4>": 128260, "<NO_Prompt>": 128261,
 }
@@ -154,6 +164,7 @@ TINY_SPECIALS = {
     "<|start_header_id|>": 306, "<|end_header_id|>": 307,
     "<|reserved_special_token_4|>": 308, "<|eot_id|>": 309,
     "<|reserved_special_token_5|>": 310, "<|reserved_special_token_6|>": 311,
+    "<|reserved_special_token_7|>": 312, "<|reserved_special_token_8|>": 313, "<|reserved_special_token_9|>": 314,
     "<Prompt0>": 320, "<Prompt1>": 321, "<Prompt2>": 322, "<Prompt3>": 323, "<Prompt4>": 324,
     "<NO_Prompt>": 325,
 }

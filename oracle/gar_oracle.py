@@ -310,8 +310,33 @@ def feature_replay(inputs_embeds: torch.Tensor, input_ids: torch.Tensor, image_f
     return (out, rois_dbg) if return_rois else out
 
 
+def feature_replay_video(inputs_embeds: torch.Tensor, input_ids: torch.Tensor, image_features: torch.Tensor,
+                         bboxes: List[dict], frame_crop_token_ids: Sequence[int], cfg):
+    """A13 — the video replay of PerceptionLMForConditionalGeneration.prepare_inputs_for_generation
+    (modeling_perception_lm.py:765-852): ``image_features`` [F, P*P, C] is one pooled map per FRAME (no thumbnail
+    drop, :772-774); frame f uses crop token ``<|reserved_special_token_{2+f}|>`` (:777-780) and RoI-aligns on its own
+    P x P map (feat_h = feat_w = P, :787-816)."""
+    P = cfg.pooled_side
+    F_ = image_features.shape[0]
+    tiles = image_features.unsqueeze(0).reshape(1, F_, P, P, -1).permute(0, 1, 4, 2, 3)     # b n c h w
+    out = []
+    for bi in range(inputs_embeds.shape[0]):
+        cur = inputs_embeds[bi]
+        for f in range(F_):
+            crop_token = int(frame_crop_token_ids[f])
+            if crop_token in input_ids[bi]:
+                idx = input_ids[bi].eq(crop_token).nonzero().squeeze()
+                head_idx, tail_idx = int(idx.min()), int(idx.max())
+                roi, ss = replay_roi(bboxes[bi][str(crop_token)], P, P, cfg.feat_stride)
+                rf = roi_align(tiles[:, f].float(), torch.tensor([roi], dtype=torch.float32), (P, P), ss, 2, True)
+                replay = rf.permute(0, 2, 3, 1).flatten(1, 2).to(tiles.dtype).squeeze(0)
+                cur = torch.cat([cur[:head_idx], replay, cur[tail_idx + 1:]])
+        out.append(cur.unsqueeze(0))
+    return torch.cat(out, dim=0)
+
+
 # =============================================================================================
-# A12  Llama (HF LlamaModel) + greedy loop             [EXT] transformers; SURVEY.md A.4
+# A12  Llama (HF LlamaModel) + greedy loop            [EXT] transformers; SURVEY.md A.4
 # =============================================================================================
 def llama_inv_freq(tcfg) -> torch.Tensor:
     """transformers.modeling_rope_utils: default + rope_type 'llama3' scaling."""
@@ -457,14 +482,17 @@ def greedy_generate(inputs_embeds: torch.Tensor, W, tcfg, max_new_tokens: int, e
 # GARModel.generate end to end                          modeling_gar.py:295-428
 # =============================================================================================
 def build_inputs_embeds(W, cfg, pixel_values, global_mask_values, aspect_ratios, bboxes, input_ids,
-                        attn_impl: str = "eager", return_intermediates: bool = False):
+                        attn_impl: str = "eager", return_intermediates: bool = False, video_frame_tokens=None):
     pixel_values = pixel_values.to(torch.float32)
     binary = decode_mask_values(global_mask_values, cfg.prompt_numbers)
     mask_embeds = mask_patch_embed(binary, W["mask_patch_embedding.weight"])
     image_features = get_image_features(pixel_values, mask_embeds, W, cfg, attn_impl)
     inputs_embeds = embed_and_scatter(input_ids, W[LM + "embed_tokens.weight"], image_features,
                                       cfg.mllm_config.image_token_id)
-    replayed = feature_replay(inputs_embeds, input_ids, image_features, aspect_ratios, bboxes, cfg)
+    if video_frame_tokens is not None:
+        replayed = feature_replay_video(inputs_embeds, input_ids, image_features, bboxes, video_frame_tokens, cfg)
+    else:
+        replayed = feature_replay(inputs_embeds, input_ids, image_features, aspect_ratios, bboxes, cfg)
     if return_intermediates:
         return replayed, {"mask_embeds": mask_embeds, "image_features": image_features,
                           "inputs_embeds_scattered": inputs_embeds}
@@ -473,12 +501,12 @@ def build_inputs_embeds(W, cfg, pixel_values, global_mask_values, aspect_ratios,
 
 def gar_generate(W, cfg, pixel_values, global_mask_values, aspect_ratios, bboxes, input_ids,
                  attention_mask=None, max_new_tokens: int = 64, eos_token_id=None,
-                 attn_impl: str = "eager", return_logits: bool = False):
+                 attn_impl: str = "eager", return_logits: bool = False, video_frame_tokens=None):
     """Restates GARModel.generate for fp32 CPU tensors. ``attention_mask`` must be all ones (the only case the
-    reference's callers produce, eval_dataset.py:143)."""
+    reference's callers produce, eval_dataset.py:143). ``video_frame_tokens`` selects the video replay (A13)."""
     if attention_mask is not None:
         assert bool((attention_mask != 0).all()), "oracle handles the unpadded case only"
     embeds = build_inputs_embeds(W, cfg, pixel_values, global_mask_values, aspect_ratios, bboxes, input_ids,
-                                 attn_impl)
+                                 attn_impl, video_frame_tokens=video_frame_tokens)
     return greedy_generate(embeds, W, cfg.mllm_config.text_config, max_new_tokens, eos_token_id, attn_impl,
                            return_logits)

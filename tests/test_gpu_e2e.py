@@ -58,6 +58,37 @@ def test_f32_greedy_parity_tiny(tiny, multi):
     assert out_g.sequences.cpu().tolist() == ref_seq.tolist()
 
 
+def _video_sample(cfg, proc, n_frames=3, dtype=torch.float32):
+    from gar_amd.eval_dataset import VideoRegionCaptionDataset
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    frames = [synthetic_image(50 + f, 180, 150) for f in range(n_frames)]
+    masks = [synthetic_mask(60 + f, 180, 150) for f in range(n_frames)]
+    return VideoRegionCaptionDataset(frames, masks, proc, data_dtype=dtype, device="cpu")[0]
+
+
+def test_f32_video_replay_parity_tiny(tiny):
+    """A13: per-frame crop tokens, one P x P map per frame, no thumbnail (modeling_perception_lm.py:765-852)."""
+    from gar_amd.modeling_gar import GARModel
+    from oracle import gar_oracle as O
+    cfg, W, proc = tiny
+    s = _video_sample(cfg, proc, 3)
+    assert s["pixel_values"].shape[0] == 3 and len(s["bboxes"][0]) == 3
+    ref_seq, ref_logits = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], None, s["bboxes"],
+                                         s["input_ids"], None, max_new_tokens=8, return_logits=True,
+                                         video_frame_tokens=s["video_frame_tokens"])
+    m = GARModel(cfg, W, torch.float32)
+    out = m.generate(**s, max_new_tokens=8, return_logits=True)
+    assert out.sequences.cpu().tolist() == ref_seq.tolist()
+    err = float((out.logits.cpu() - ref_logits).abs().max())
+    assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
+    # the replayed rows equal the oracle's (and differ from the image-path replay of the same inputs)
+    feats = m.get_image_features(s["pixel_values"], s["global_mask_values"])
+    emb = m.build_inputs_embeds(s["input_ids"], feats, s["bboxes"], None, 3, True, s["video_frame_tokens"]).cpu().clone()
+    ref_emb = O.build_inputs_embeds(W, cfg, s["pixel_values"], s["global_mask_values"], None, s["bboxes"], s["input_ids"],
+                                    video_frame_tokens=s["video_frame_tokens"])
+    assert _rel_l2(emb, ref_emb) < 1e-5
+
+
 def test_f32_intermediates_tiny(tiny):
     from gar_amd.modeling_gar import GARModel
     from oracle import gar_oracle as O

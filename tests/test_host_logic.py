@@ -82,6 +82,35 @@ def test_sample_contract_full_size():
     assert sorted(mv.unique().tolist()) == [1, 5]
 
 
+def test_video_sample_contract_and_oracle_replay():
+    """A13 builder + oracle: F frames -> F single tiles, F*P*P image placeholders, one crop run and bbox per frame;
+    the oracle's video replay writes convex blends of the frame's own pooled tokens."""
+    from gar_amd.eval_dataset import VideoRegionCaptionDataset
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    from oracle import gar_oracle as O
+    cfg = GARConfig.tiny()
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+    F_ = 6
+    frames = [synthetic_image(f, 150, 120) for f in range(F_)]
+    masks = [synthetic_mask(f, 150, 120) for f in range(F_)]
+    s = VideoRegionCaptionDataset(frames, masks, proc, data_dtype=torch.float32, device="cpu")[0]
+    P2 = cfg.tokens_per_tile
+    assert s["pixel_values"].shape == (F_, 3, 112, 112) and s["global_mask_values"].shape == (F_, 3, 112, 112)
+    assert int((s["input_ids"] == cfg.mllm_config.image_token_id).sum()) == F_ * P2
+    assert s["video_frame_tokens"] == [304, 305, 308, 310, 311, 312]
+    for t in s["video_frame_tokens"]:
+        assert int((s["input_ids"] == t).sum()) == P2 and str(t) in s["bboxes"][0]
+    C = 4
+    feats = torch.zeros(F_, P2, C)
+    for f in range(F_):
+        feats[f, :, 0] = float(f + 1)                 # constant map per frame -> replay rows equal f+1
+    emb = torch.zeros(1, s["input_ids"].shape[1], C)
+    out = O.feature_replay_video(emb, s["input_ids"], feats, s["bboxes"], s["video_frame_tokens"], cfg)
+    for f, t in enumerate(s["video_frame_tokens"]):
+        rows = out[0][s["input_ids"][0] == t]
+        assert torch.allclose(rows[:, 0], torch.full((P2,), float(f + 1)), atol=1e-6)
+
+
 def test_tokenizer_roundtrip_and_special_ids():
     tk = StubTokenizer()
     assert tk.convert_tokens_to_ids("<|reserved_special_token_3|>") == 128005

@@ -14,7 +14,11 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
           ("vit fc1", 139400, 4096, 1024, hip.EPI_BIAS_GELU), ("vit fc2", 139400, 1024, 4096, hip.EPI_BIAS_SCALE_RES),
           ("llm qkv", 37744, 3072, 2048, hip.EPI_NONE), ("llm o", 37744, 2048, 2048, hip.EPI_RES),
           ("llm gate/up", 37744, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 37744, 2048, 8192, hip.EPI_RES),
-          ("square 8k", 8192, 8192, 8192, hip.EPI_NONE)]
+          ("square 8k", 8192, 8192, 8192, hip.EPI_NONE),
+          ("proj none", 139400, 1024, 1024, hip.EPI_NONE), ("proj bias", 139400, 1024, 1024, hip.EPI_BIAS),
+          ("qkv nodephase", 139400, 3072, 1024, -2), ("proj nodephase", 139400, 1024, 1024, -2),
+          ("proj nostore", 139400, 1024, 1024, -1), ("qkv nostore", 139400, 3072, 1024, -1),
+          ("llm o nostore", 37744, 2048, 2048, -1)]
 
 
 def main():
@@ -27,6 +31,12 @@ def main():
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
         kw = {}
+        if epi == -1:                       # debug: main loop only (no epilogue)
+            epi = hip.EPI_NONE
+            kw["tokens_out"] = -12345
+        if epi == -2:                       # debug: every tile stores into the first tile's (L2-resident) region
+            epi = hip.EPI_NONE
+            kw["tokens_out"] = -12346
         if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
         if epi in (hip.EPI_BIAS_SCALE_RES, hip.EPI_RES):
