@@ -15,6 +15,7 @@
 #include "gemm_epilogue.h"
 
 bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s);   // gemm_pp.hip
+bool gar_skinny_bf16_try(const gar_gemm_params& p, hipStream_t s);   // gemm_skinny.hip
 
 // ===============================================================================================================
 // bf16: 128 x 128 x 64
@@ -409,6 +410,7 @@ static int pick_waves(int n_blocks, int ksteps) {
 
 template <int EPI>
 static int launch(int dtype, const gar_gemm_params& p, hipStream_t s) {
+    if (dtype == GAR_BF16 && p.M <= 64 && gar_skinny_bf16_try(p, s)) return GAR_OK;   // gemm_skinny.hip
     if (p.M <= 16) {
         constexpr int NT = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
         const int nb = (p.N + 16 * NT - 1) / (16 * NT);
@@ -454,7 +456,10 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
     if (e == GAR_EPI_BIAS_SCALE_RES) GAR_CHECK_ARG(p.gamma && p.residual, "gar_gemm: SCALE_RES needs gamma+residual");
     if (e == GAR_EPI_RES) GAR_CHECK_ARG(p.residual && p.N % 4 == 0, "gar_gemm: RES needs residual");
     if (e == GAR_EPI_SWIGLU) GAR_CHECK_ARG(p.N % 32 == 0, "gar_gemm: SWIGLU needs N%%32==0");
-    if (p.norm_w) GAR_CHECK_ARG(p.M <= 16, "gar_gemm: fused RMSNorm prologue is built for the decode path (M <= 16) only");
+    if (p.norm_w)
+        GAR_CHECK_ARG(p.M <= (dtype == GAR_BF16 ? 64 : 16) &&
+                          (e == GAR_EPI_NONE || e == GAR_EPI_RES || e == GAR_EPI_SWIGLU || e == GAR_EPI_BIAS),
+                      "gar_gemm: fused RMSNorm prologue is built for the decode path only (M <= 64 bf16 / 16 f32)");
     if (e == GAR_EPI_PATCH_POS)
         GAR_CHECK_ARG(p.pos && p.tokens_in > 0 && p.tokens_out >= p.tokens_in + p.token_offset && p.N % 4 == 0,
                       "gar_gemm: PATCH_POS args");

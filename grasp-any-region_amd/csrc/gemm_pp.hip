@@ -362,7 +362,9 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
         (p.residual && (!al16(p.residual) || (p.ldr % 8) != 0)) || (p.pos && !al16(p.pos)))
         return false;
     // buffer descriptors address each operand with 32-bit byte offsets
-    if (((int64_t)(p.M - 1) * p.lda + p.K) * 2 >= (int64_t)1 << 31 || ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 >= (int64_t)1 << 31)
+    // (num_records and voffset are unsigned 32-bit: operands up to 4 GiB)
+    if (((int64_t)(p.M - 1) * p.lda + p.K) * 2 >= ((int64_t)1 << 32) - 4096 ||
+        ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 >= ((int64_t)1 << 32) - 4096)
         return false;
     switch (p.epilogue) {
         case GAR_EPI_NONE: launch_pp<GAR_EPI_NONE>(p, pm, pn, num_cus, s); break;

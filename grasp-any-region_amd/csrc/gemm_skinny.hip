@@ -1,0 +1,181 @@
+// Skinny bf16 GEMM for the decode step: C[M <= 64, N] = epilogue(RMSNorm?(A) W^T), weight-streaming (HBM-bound).
+//
+//   Block = 16 (32 for SwiGLU) weight rows x all of K; its waves split K; each wave keeps MT = ceil(M/16) MFMA
+//   accumulators per weight tile so ONE pass over the weights serves up to 64 sequences (continuous batching of
+//   regions amortises the 2.47 GB/token weight stream).
+//   Per 64-wide K step lane (row = l&15, g = l>>4) reads W[row][k0+16g .. +16) as two adjacent nontemporal 16-B loads
+//   (the four g's of a row cover one 128-B line) and x[16 mt + (l&15)][same k] from L2; MFMA h uses the h-th 8-element
+//   half of both. NORM: x*g is the operand and rsqrt(mean(x^2)+eps) scales the accumulator row in the epilogue.
+//   The waves' partial accumulators are merged in LDS, row tile mt by wave (mt mod nw).
+//   Algorithmic bytes per launch = N*K*2 (weights) + small.
+#include "gemm_epilogue.h"
+
+template <int EPI, int NT, int MT, bool NORM>
+__global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* red = reinterpret_cast<float*>(smem);                  // [nw][NT*MT][64][4]
+    float* red_ss = red + nw * NT * MT * 256;                     // [nw][MT][16]
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NT;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* X = (const bf16_t*)p.A;
+    const bf16_t* Gw = (const bf16_t*)p.norm_w;
+    const int ksteps = p.K / 64;
+    const int per = (ksteps + nw - 1) / nw;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const bf16_t* xp[MT];
+    bool xv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        xv[mt] = mt * 16 + frow < p.M;
+        xp[mt] = X + (int64_t)(xv[mt] ? mt * 16 + frow : 0) * p.lda + fq * 16;
+    }
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)min(n0 + t * 16 + frow, p.N - 1) * p.ldw + fq * 16;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssq[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ssq[mt] = 0.f;
+
+    auto step = [&](int ks) {
+        const int k0 = ks * 64;
+        bf16x8 w0[NT], w1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            w0[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k0));
+            w1[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k0 + 8));
+        }
+        float ga[8], gb[8];
+        if (NORM) {
+            ld8(Gw + fq * 16 + k0, ga);
+            ld8(Gw + fq * 16 + k0 + 8, gb);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 x0, x1;
+            if (NORM) {
+                float xa[8], xb[8];
+                ld8(xp[mt] + k0, xa);
+                ld8(xp[mt] + k0 + 8, xb);
+                u32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    ssq[mt] += xa[e] * xa[e] + xa[e + 1] * xa[e + 1] + xb[e] * xb[e] + xb[e + 1] * xb[e + 1];
+                    pa[e >> 1] = pack_bf2(xa[e] * ga[e], xa[e + 1] * ga[e + 1]);
+                    pb[e >> 1] = pack_bf2(xb[e] * gb[e], xb[e + 1] * gb[e + 1]);
+                }
+                x0 = __builtin_bit_cast(bf16x8, pa);
+                x1 = __builtin_bit_cast(bf16x8, pb);
+            } else {
+                x0 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0);
+                x1 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0 + 8);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[t], x0, acc[t][mt], 0, 0, 0);
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t], x1, acc[t][mt], 0, 0, 0);
+            }
+        }
+    };
+    int ks = ks0;
+    for (; ks + 2 <= ks1; ks += 2) {
+        step(ks);
+        step(ks + 1);
+    }
+    for (; ks < ks1; ++ks) step(ks);
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(red + (((wave * NT + t) * MT + mt) * 64 + lane) * 4) = acc[t][mt];
+    if (NORM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float s = ssq[mt];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) red_ss[(wave * MT + mt) * 16 + lane] = s;
+        }
+    }
+    __syncthreads();
+    // row tile mt is finished by wave (mt mod nw)
+    for (int mt = wave; mt < MT; mt += nw) {
+        const int m = mt * 16 + frow;
+        float v[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[t][r] = 0.f;
+            for (int w = 0; w < nw; ++w) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(red + (((w * NT + t) * MT + mt) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[t][r] += a[r];
+            }
+        }
+        if (NORM) {
+            float tot = 0.f;
+            for (int w = 0; w < nw; ++w) tot += red_ss[(w * MT + mt) * 16 + frow];
+            const float rstd = rsqrtf(tot / (float)p.K + p.norm_eps);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
+        }
+        if (m >= p.M) continue;
+        if (EPI == GAR_EPI_SWIGLU) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = silu(v[0][r]) * v[NT - 1][r];
+            epilogue_store<bf16_t, EPI>(p, m, (n0 >> 1) + fq * 4, o);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + fq * 4;
+                if (n < p.N) epilogue_store<bf16_t, EPI>(p, m, n, v[t]);
+            }
+        }
+    }
+}
+
+template <int EPI, int MT>
+static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
+    constexpr int NT = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
+    const int nb = (p.N + 16 * NT - 1) / (16 * NT);
+    const int ksteps = p.K / 64;
+    // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, reduction buffer <= 64 KiB
+    int nw = 4;
+    while (nw < 16 && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && (nw * 2) * NT * MT * 1024 + (nw * 2) * MT * 64 <= 65536)
+        nw *= 2;
+    const int lds = nw * NT * MT * 1024 + nw * MT * 64;
+    if (p.norm_w)
+        hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
+    else
+        hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
+}
+
+template <int EPI>
+static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
+    if (p.M <= 16) launch_skinny<EPI, 1>(p, s);
+    else if (p.M <= 32) launch_skinny<EPI, 2>(p, s);
+    else launch_skinny<EPI, 4>(p, s);
+}
+
+// bf16, M <= 64, the epilogues the decode step uses. Returns false otherwise.
+bool gar_skinny_bf16_try(const gar_gemm_params& p, hipStream_t s) {
+    if (p.M > 64) return false;
+    switch (p.epilogue) {
+        case GAR_EPI_NONE: launch_skinny_m<GAR_EPI_NONE>(p, s); return true;
+        case GAR_EPI_RES: launch_skinny_m<GAR_EPI_RES>(p, s); return true;
+        case GAR_EPI_SWIGLU: launch_skinny_m<GAR_EPI_SWIGLU>(p, s); return true;
+        case GAR_EPI_BIAS: launch_skinny_m<GAR_EPI_BIAS>(p, s); return true;
+        default: return false;
+    }
+}

@@ -78,6 +78,7 @@ class GARModel:
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
         self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
+        self.prefill_chunk = 16      # regions per vision-tower / prefill pass (decode serves all B at once)
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
@@ -322,7 +323,8 @@ class GARModel:
         )
         return key, st
 
-    def _prefill(self, embeds: torch.Tensor, st, Smax: int):
+    def _prefill(self, embeds: torch.Tensor, st, Smax: int, b0: int = 0):
+        """Prefill of one chunk of sequences [B,S,C] whose KV goes to rows b0..b0+B of the shared cache."""
         t = self.config.mllm_config.text_config
         B, S, C_l = embeds.shape
         Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
@@ -337,18 +339,20 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         for li, ly in enumerate(self.layers):
+            Kc, Vtc = st["Kc"][li][b0:b0 + B], st["Vtc"][li][b0:b0 + B]       # this chunk's rows of the shared cache
             ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
             ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale)
-            ops.attention(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
+            ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale)
+            ops.attention(Q, Kc, Vtc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
             ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
             ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
             ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
 
-    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, logits_keep=None):
+    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None):
         """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed)."""
+        cur = st["cur"] if cur is None else cur
         t = self.config.mllm_config.text_config
         C_l, V = t.hidden_size, t.vocab_size
         key = ("head", B)
@@ -356,12 +360,12 @@ class GARModel:
         Vld = _round_up(V, 64)
         logits = self._buf(key, "logits", (B, Vld))
         ws = self._buf(key, "amws", (ops.argmax_workspace(B, V),), torch.uint8)
-        if B <= 16:
+        if B <= 16:         # RMSNorm folded into the GEMV prologue; for more rows one tiny norm launch is cheaper
             ops.gemm(last_rows, self.lm_head, logits, norm_w=self.final_norm, norm_eps=t.rms_norm_eps)
         else:
             ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
             ops.gemm(xn, self.lm_head, logits)
-        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], st["cur"], ws)
+        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws)
         return logits
 
     def _decode_step(self, st, B: int, Smax: int, out_tokens):
@@ -382,7 +386,7 @@ class GARModel:
         nsplit = max(1, min(64, 512 // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
-        fuse = B <= 16                      # RMSNorm folded into the skinny GEMM prologue (no separate launch)
+        fuse = B <= 16     # RMSNorm folded into the skinny GEMM prologue (every block redoes x*g: only pays for <= 16 rows)
         for li, ly in enumerate(self.layers):
             if fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
@@ -430,29 +434,43 @@ class GARModel:
         B, S = input_ids.shape
         if validate and attention_mask is not None and not bool((attention_mask != 0).all()):
             raise hip.GarError("padded attention_mask is not supported (the reference's callers pass all ones)")
+        Smax = _round_up(S + max_new_tokens, 64)
+        skey, st = self._llm_state(B, Smax)
+        out_tokens = self._buf(skey, "out_tokens", (B, max_new_tokens), torch.int64, zero=True)
+        st["counters"].zero_()
+        V = cfg.mllm_config.text_config.vocab_size
+        tiles = 0
         if pixel_values is not None:
             tiles = pixel_values.shape[0] // B if pixel_values.dim() == 4 else pixel_values.shape[1]
-            feats = self.get_image_features(pixel_values, global_mask_values)
+            pv = pixel_values.reshape(B, tiles, *pixel_values.shape[-3:])
+            gm = None if global_mask_values is None else global_mask_values.reshape(pv.shape)
             if feature_replay_video and video_frame_tokens is None:
                 # <|reserved_special_token_{2+f}|> of frame f (modeling_perception_lm.py:777-780): the first
                 # prompt_numbers ids are config.crop_tokens_ids, the following reserved tokens are consecutive ids
                 base = list(self.crop_tokens_ids)
                 video_frame_tokens = (base + [base[-1] + 1 + i for i in range(max(0, tiles - len(base)))])[:tiles]
-            embeds = self.build_inputs_embeds(input_ids, feats, bboxes, aspect_ratios, tiles, validate,
-                                              video_frame_tokens if feature_replay_video else None)
-        else:
-            ids = input_ids.to(self.device, torch.int64).contiguous()
-            embeds = self._buf(("emb", B, S), "embeds", (B, S, cfg.mllm_config.text_config.hidden_size))
-            ops.embed_assemble(ids, None, self.E, None, embeds, 0)
-        Smax = _round_up(S + max_new_tokens, 64)
-        skey, st = self._llm_state(B, Smax)
-        out_tokens = self._buf(skey, "out_tokens", (B, max_new_tokens), torch.int64, zero=True)
-        st["counters"].zero_()
-        last = self._prefill(embeds, st, Smax)
+        # vision tower + prefill run over chunks of <= prefill_chunk regions (bounded activation memory, GEMM operands
+        # < 4 GiB); the decode loop below then serves all B sequences of the shared KV cache in one weight pass per token
+        first_logits = []
+        chunk = max(1, min(B, self.prefill_chunk))
+        for b0 in range(0, B, chunk):
+            b1 = min(B, b0 + chunk)
+            ids_c = input_ids[b0:b1]
+            if pixel_values is not None:
+                feats = self.get_image_features(pv[b0:b1], None if gm is None else gm[b0:b1])
+                ar_c = None if aspect_ratios is None else aspect_ratios[b0:b1]
+                embeds = self.build_inputs_embeds(ids_c, feats, bboxes[b0:b1], ar_c, tiles, validate,
+                                                  video_frame_tokens if feature_replay_video else None)
+            else:
+                embeds = self._buf(("emb", b1 - b0, S), "embeds", (b1 - b0, S, cfg.mllm_config.text_config.hidden_size))
+                ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)
+            last = self._prefill(embeds, st, Smax, b0)
+            lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1])
+            if return_logits:
+                first_logits.append(lg[:, :V].float().clone())
         all_logits = []
-        lg = self._head(last, B, out_tokens, st)
         if return_logits:
-            all_logits.append(lg[:, :cfg.mllm_config.text_config.vocab_size].float().clone())
+            all_logits.append(torch.cat(first_logits, 0))
         # counters after prefill: pos = S (position of the next token), kv_len = S+1 (incl. it), step = 1
         st["counters"].copy_(torch.tensor([S, S + 1, 1, 0], dtype=torch.int32), non_blocking=False)
         eos = set()

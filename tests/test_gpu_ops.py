@@ -405,6 +405,40 @@ def test_skinny_gemm_with_fused_rmsnorm(dev, dt, epi):
         close(out, F.silu(n @ gw.double().T) * (n @ uw.double().T), dt, extra=2.0)
 
 
+@pytest.mark.parametrize("M", [17, 32, 40, 64])
+def test_skinny_gemm_batched_rows_bf16(dev, M):
+    """decode GEMMs for up to 64 batched sequences: 2 / 4 accumulator row tiles per weight tile, all decode epilogues,
+    with and without the fused RMSNorm."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    K, N = 2048, 768
+    x = q(rnd(M, K, seed=60, scale=2.0), dt)
+    g = q(1 + 0.1 * rnd(K, seed=61), dt)
+    w = q(rnd(N, K, seed=62, scale=K ** -0.5), dt)
+    res = q(rnd(M, N, seed=63), dt)
+    xd, wd = x.double(), w.double()
+    nrm = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * g.double()
+    out = torch.empty(M, N, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), w.to(dev, dt), out)
+    close(out, xd @ wd.T, dt)
+    ops.gemm(x.to(dev, dt), w.to(dev, dt), out, norm_w=g.to(dev, dt), norm_eps=1e-5)
+    close(out, nrm @ wd.T, dt, extra=2.0)
+    r = res.to(dev, dt).clone()
+    ops.gemm(x.to(dev, dt), w.to(dev, dt), r, hip.EPI_RES, residual=r)
+    close(r, res.double() + xd @ wd.T, dt)
+    Fd = N // 2
+    gw, uw = w[:Fd], w[Fd:]
+    gu = torch.stack([gw.view(Fd // 16, 16, K), uw.view(Fd // 16, 16, K)], 1).reshape(N, K)
+    o2 = torch.empty(M, Fd, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), gu.to(dev, dt), o2, hip.EPI_SWIGLU, norm_w=g.to(dev, dt), norm_eps=1e-5)
+    close(o2, F.silu(nrm @ gw.double().T) * (nrm @ uw.double().T), dt, extra=2.0)
+    # a row's result does not depend on the batch it rides in (up to the split-K summation order)
+    o1 = torch.empty(1, N, dtype=dt, device=dev)
+    ops.gemm(x[M - 1:M].to(dev, dt).contiguous(), w.to(dev, dt), o1)
+    ops.gemm(x.to(dev, dt), w.to(dev, dt), out)
+    close(o1[0], out[M - 1].float(), dt)
+
+
 def test_abi_errors_are_reported_not_thrown(dev):
     from gar_amd import hip, ops
     a = torch.zeros(4, 60, device=dev)
