@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             BAR_THEN_WAIT_LDS()
             MMA(1, 1)
             BAR()
-            // ---- phase 3
+            // ---- phase 3 (B0 is re-read: keeping both B sub-tiles live costs 16 VGPRs and spills — measured, no gain)
             READ_B(st, 0)
             if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 1: before the barrier both rows share
             BAR_THEN_WAIT_LDS()

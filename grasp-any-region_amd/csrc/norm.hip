@@ -2,9 +2,10 @@
 // HBM-bound: algorithmic bytes = 2 * M * D * sizeof(T).
 #include "common.h"
 
-#define NORM_MAXC 8   // register-cached chunks of 512 elements -> D <= 4096 stays in registers (one HBM read)
+// MAXC = register-cached chunks of 512 elements (rows up to 512*MAXC stay in registers: one HBM read); instantiated
+// for 2 / 4 / 8 so short rows (ViT D=1024) keep the VGPR count — and with it the occupancy that hides HBM latency — low
 
-template <typename T, bool RMS>
+template <typename T, bool RMS, int NORM_MAXC>
 __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ w,
                                                    const T* __restrict__ b, int M, int D, int64_t ldx, int64_t ldy, float eps) {
     const int lane = threadIdx.x & 63;
@@ -110,12 +111,15 @@ static int launch_norm(int dtype, const void* x, void* y, const void* w, const v
     GAR_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0, "norm: row strides must be multiples of 8 elements");
     dim3 grid((M + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GAR_BF16)
-        hipLaunchKernelGGL((norm_kernel<bf16_t, RMS>), grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)w,
-                           (const bf16_t*)b, M, D, ldx, ldy, eps);
-    else
-        hipLaunchKernelGGL((norm_kernel<float, RMS>), grid, block, 0, s, (const float*)x, (float*)y, (const float*)w,
-                           (const float*)b, M, D, ldx, ldy, eps);
+#define LAUNCH_NORM(TT, C_)                                                                                    \
+    hipLaunchKernelGGL((norm_kernel<TT, RMS, C_>), grid, block, 0, s, (const TT*)x, (TT*)y, (const TT*)w, (const TT*)b, M, \
+                       D, ldx, ldy, eps)
+    if (dtype == GAR_BF16) {
+        if (D <= 1024) LAUNCH_NORM(bf16_t, 2); else if (D <= 2048) LAUNCH_NORM(bf16_t, 4); else LAUNCH_NORM(bf16_t, 8);
+    } else {
+        if (D <= 1024) LAUNCH_NORM(float, 2); else if (D <= 2048) LAUNCH_NORM(float, 4); else LAUNCH_NORM(float, 8);
+    }
+#undef LAUNCH_NORM
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }
