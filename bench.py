@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GAR_BENCH_BATCH", "16")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GAR_BENCH_BATCH", "64")),
                     help="regions per step per GPU (continuous batching of independent regions)")
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--max-num-tiles", type=int, default=16)
@@ -168,11 +168,21 @@ def main():
     roof = None
     if "gemm_tile_bf16" in agg:
         fl, nb, sec, cnt = agg["gemm_tile_bf16"]
-        roof = {"kernel": "gemm_bf16_kernel (ViT qkv/proj/fc1/fc2, patch-embed, projector, Llama prefill qkv/o/gate-up/down)",
+        roof = {"kernel": "gemm_bf16_pp_kernel (ViT qkv/proj/fc1/fc2, patch-embed, projector, Llama prefill qkv/o/gate-up/down)",
                 "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
                 "launches": cnt, "avg_launch_us": sec / cnt * 1e6, "flop_per_launch": fl / cnt,
-                "time_share_of_step": sec / (elapsed if world == 1 else elapsed)}
+                "algorithmic_bytes_per_launch": nb / cnt, "time_share_of_step": sec / elapsed}
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                k = json.load(open(pmc))["kernels"]["gemm_bf16_pp_kernel"]
+                roof["traffic"] = k["traffic_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            except Exception:
+                pass
     value = world * args.steps * B / elapsed
     line = {"metric": "regions/sec (1024^2 img, 1 mask, 64-tok caption) GAR-1B", "value": value, "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

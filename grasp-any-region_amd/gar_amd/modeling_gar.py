@@ -13,6 +13,7 @@ bookkeeping runs on the device, so ``generate`` has no host sync before the firs
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -477,7 +478,7 @@ class GARModel:
         if eos_token_id is not None:
             eos = set(int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]))
         graph = None
-        if use_graph and not return_logits and max_new_tokens > 1:
+        if use_graph and not return_logits and max_new_tokens > 1 and os.environ.get("GAR_NO_GRAPH") != "1":
             graph = self._decode_graph(st, B, Smax, out_tokens, skey)
         n_done = 1
         finished_at = [None] * B
