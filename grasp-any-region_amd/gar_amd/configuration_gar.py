@@ -244,14 +244,15 @@ class GARConfig:
             "vision_use_cls_token": True, "projector_pooling_ratio": 2,
             "image_token_id": 300, "video_token_id": 301,
         }
-        return cls(mllm_config=_apply(d, over), prompt_numbers=5,
-                   crop_tokens_ids=[304, 305, 308, 310, 311])
+        d = _apply(d, over)
+        d["vision_config"]["num_features"] = d["vision_config"]["model_args"]["embed_dim"]
+        return cls(mllm_config=d, prompt_numbers=5, crop_tokens_ids=[304, 305, 308, 310, 311])
 
 
 def _apply(d, over):
     """over: {"vision.depth": 2, "text.num_hidden_layers": 2, ...} shallow overrides."""
     for k, val in over.items():
-        sec, key = k.split(".", 1)
+        sec, _, key = k.partition(".")
         if sec == "vision":
             d["vision_config"]["model_args"][key] = val
         elif sec == "text":

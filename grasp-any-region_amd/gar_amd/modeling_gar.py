@@ -141,18 +141,44 @@ class GARModel:
         self.pos = d(W[VT + "pos_embed"].reshape(-1, D))
         self.norm_pre = (d(W[VT + "norm_pre.weight"]), d(W[VT + "norm_pre.bias"]))
         self.vblocks = []
+        # The attention kernels are built for head_dim 64 and 128. Other head dims (PE-G/14: 96) run zero-padded to the
+        # next built size: padded q/k/v rows of the fused qkv weight and bias and padded input columns of the output
+        # projection are zero (and the RoPE table rotates them by the identity), so scores and outputs are unchanged.
+        H, hd = v.num_heads, v.head_dim
+        if hd > 128:
+            raise hip.GarError(f"vision head_dim {hd} > 128 is not built")
+        self.v_hd = hdp = hd if hd in (64, 128) else (64 if hd < 64 else 128)
+
+        def pad_qkv(w):          # [3*H*hd, ...] -> [3*H*hdp, ...]
+            if hdp == hd:
+                return w
+            w = w.reshape(3, H, hd, *w.shape[1:])
+            out = w.new_zeros(3, H, hdp, *w.shape[3:])
+            out[:, :, :hd] = w
+            return out.reshape(3 * H * hdp, *w.shape[3:])
+
+        def pad_proj(w):         # [D, H*hd] -> [D, H*hdp]
+            if hdp == hd:
+                return w
+            out = w.new_zeros(w.shape[0], H, hdp)
+            out[:, :, :hd] = w.reshape(w.shape[0], H, hd)
+            return out.reshape(w.shape[0], H * hdp)
+
         for i in range(v.depth):
             b = f"{VT}blocks.{i}."
             self.vblocks.append(dict(
                 n1=(d(W[b + "norm1.weight"]), d(W[b + "norm1.bias"])),
-                qkv_w=d(W[b + "attn.qkv.weight"]), qkv_b=d(W[b + "attn.qkv.bias"]),
-                proj_w=d(W[b + "attn.proj.weight"]), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
+                qkv_w=d(pad_qkv(W[b + "attn.qkv.weight"])), qkv_b=d(pad_qkv(W[b + "attn.qkv.bias"])),
+                proj_w=d(pad_proj(W[b + "attn.proj.weight"])), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
                 n2=(d(W[b + "norm2.weight"]), d(W[b + "norm2.bias"])),
                 fc1_w=d(W[b + "mlp.fc1.weight"]), fc1_b=d(W[b + "mlp.fc1.bias"]),
                 fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"])))
         self.pj = dict(w1=d(W[PJ + "linear_1.weight"]), b1=d(W[PJ + "linear_1.bias"]),
                        w2=d(W[PJ + "linear_2.weight"]), b2=d(W[PJ + "linear_2.bias"]))
         sin, cos = _rope2d_tables(v)
+        if hdp != hd:
+            sin = torch.nn.functional.pad(sin, (0, hdp - hd), value=0.0).contiguous()
+            cos = torch.nn.functional.pad(cos, (0, hdp - hd), value=1.0).contiguous()
         self.vit_sin, self.vit_cos = sin.to(self.device), cos.to(self.device)
         self.E = d(W[LM + "embed_tokens.weight"])
         self.lm_head = self.E if t.tie_word_embeddings or "mllm.lm_head.weight" not in W else d(W["mllm.lm_head.weight"])
@@ -204,18 +230,19 @@ class GARModel:
         if global_mask_values is not None:
             msk = global_mask_values.to(self.device, self.dtype).reshape(pix.shape).contiguous()
         Tt = pix.shape[0]
-        n, D, Dm, H, hd = v.num_patches, v.embed_dim, v.mlp_dim, v.num_heads, v.head_dim
+        n, D, Dm, H, hd = v.num_patches, v.embed_dim, v.mlp_dim, v.num_heads, self.v_hd     # hd: padded head dim
+        Da = H * hd
         N = n + self.npt
         Npad = _round_up(N, 64)
         key = ("vit", Tt)
         A = self._buf(key, "im2col", (Tt * n, self.Kp))
         x = self._buf(key, "x", (Tt, N, D))
         hbuf = self._buf(key, "h", (Tt * N, D))
-        qkv = self._buf(key, "qkv", (Tt * N, 3 * D))
+        qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
         Q = self._buf(key, "Q", (Tt, H, Npad, hd))
         K = self._buf(key, "K", (Tt, H, Npad, hd))
         Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
-        att = self._buf(key, "att", (Tt * N, D))
+        att = self._buf(key, "att", (Tt * N, Da))
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
         x2 = x.view(Tt * N, D)
@@ -223,7 +250,7 @@ class GARModel:
         if self.npt:
             ops.cls_pos_fill(x, self.cls, self.pos)
         ops.layernorm(x2, *self.norm_pre, v.ln_eps)
-        q_scale = (hd ** -0.5) * LOG2E
+        q_scale = (v.head_dim ** -0.5) * LOG2E
         for blk in self.vblocks:
             ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
             ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])

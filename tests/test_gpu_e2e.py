@@ -216,3 +216,60 @@ def test_full_size_bf16_properties():
                aspect_ratios=torch.cat([s["aspect_ratios"]] * 2))
     c = m.generate(**two, max_new_tokens=8)
     assert torch.equal(c.sequences[0], c.sequences[1]) and torch.equal(c.sequences[0], a.sequences[0])
+
+
+def _tiny_8b_like():
+    """GAR-8B's structure at tiny sizes: PE-G style ViT (head_dim 96, NO cls token), Llama-3.1-8B style text model
+    (head_dim 128, GQA 4:1, untied lm_head)."""
+    from gar_amd import GARConfig
+    return GARConfig.tiny(**{"vision.embed_dim": 192, "vision.num_heads": 2, "vision.mlp_dim": 448,
+                             "vision_use_cls_token": False,
+                             "text.hidden_size": 256, "text.num_attention_heads": 4, "text.num_key_value_heads": 1,
+                             "text.head_dim": 128, "text.intermediate_size": 448, "text.tie_word_embeddings": False})
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gar8b_structure_tiny(dtype):
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = _tiny_8b_like()
+    assert cfg.mllm_config.vision_config.head_dim == 96 and not cfg.mllm_config.vision_use_cls_token
+    W = synthetic_weights(cfg)
+    assert "mllm.lm_head.weight" in W
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+    s = _sample(cfg, proc, 2, dtype=dtype)
+    Wq = {k: v.to(dtype).float() for k, v in W.items()}
+    ref_seq, ref_logits = _oracle(Wq, cfg, s, 8)
+    m = GARModel(cfg, W, dtype)
+    out = m.generate(**s, max_new_tokens=8, return_logits=True)
+    if dtype == torch.float32:
+        assert out.sequences.cpu().tolist() == ref_seq.tolist()
+        err = float((out.logits.cpu() - ref_logits).abs().max())
+        assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
+    else:
+        assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
+    g = m.generate(**s, max_new_tokens=8)
+    assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
+
+
+def test_bf16_gar8b_dims_one_layer():
+    """GAR-8B shapes (BASELINE.json configs[3]: PE-G/14 ViT 1536 wide / 16 heads x 96 / MLP 8960 / no cls token,
+    Llama-3.1-8B 4096 wide / 32 q + 8 kv heads x 128 / FFN 14336 / untied head; max_num_tiles=8 -> 5 tiles) with one
+    layer each, bf16 against the f32 oracle on the bf16-rounded weights."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_8b(**{"vision.depth": 1, "text.num_hidden_layers": 1})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=8)
+    s = _sample(cfg, proc, 0, 1024, 1024, dtype=torch.bfloat16)
+    assert s["pixel_values"].shape[0] == 5
+    Wq = {k: v.to(torch.bfloat16).float() for k, v in W.items()}
+    ref_seq, ref_logits = _oracle(Wq, cfg, s, 2, attn_impl="sdpa")
+    m = GARModel(cfg, W, torch.bfloat16)
+    out = m.generate(**s, max_new_tokens=2, return_logits=True)
+    assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
+    g = m.generate(**s, max_new_tokens=2)
+    assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
