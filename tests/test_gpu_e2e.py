@@ -273,3 +273,47 @@ def test_bf16_gar8b_dims_one_layer():
     assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
     g = m.generate(**s, max_new_tokens=2)
     assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
+
+
+def test_f32_parity_gar1b_dims_multi_region_one_layer():
+    """BASELINE.json configs[2]: 4 masks per 1024^2 image, relationship prompt, GAR-1B shapes (one layer each):
+    four 256-row RoI replays spliced into one ~5.5k-token sequence, f32 token parity with the oracle."""
+    from gar_amd import GARConfig
+    from gar_amd.eval_dataset import MultiRegionDataset
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.synthetic import RELATIONSHIP_QUESTION, synthetic_disjoint_masks, synthetic_image
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b(**{"vision.depth": 1, "text.num_hidden_layers": 1})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16)
+    s = MultiRegionDataset(synthetic_image(3), synthetic_disjoint_masks(3, 4), RELATIONSHIP_QUESTION, proc,
+                           data_dtype=torch.float32, device="cpu")[0]
+    assert s["pixel_values"].shape[0] == 17 and len(s["bboxes"][0]) == 4
+    ref_seq, ref_logits = _oracle(W, cfg, s, 3, attn_impl="sdpa")
+    m = GARModel(cfg, W, torch.float32)
+    out = m.generate(**s, max_new_tokens=3, return_logits=True)
+    err = float((out.logits.cpu() - ref_logits).abs().max())
+    assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
+    assert out.sequences.cpu().tolist() == ref_seq.tolist()
+
+
+def test_f32_video_replay_gar8b_structure_tiny():
+    """BASELINE.json configs[4] structure: video replay (8 frames, per-frame mask) on the GAR-8B-like tiny config."""
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    from oracle import gar_oracle as O
+    cfg = _tiny_8b_like()
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+    s = _video_sample(cfg, proc, 8)
+    assert s["pixel_values"].shape[0] == 8 and len(s["bboxes"][0]) == 8
+    ref_seq, ref_logits = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], None, s["bboxes"],
+                                         s["input_ids"], None, max_new_tokens=6, return_logits=True,
+                                         video_frame_tokens=s["video_frame_tokens"])
+    m = GARModel(cfg, W, torch.float32)
+    out = m.generate(**s, max_new_tokens=6, return_logits=True)
+    assert out.sequences.cpu().tolist() == ref_seq.tolist()
+    err = float((out.logits.cpu() - ref_logits).abs().max())
+    assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
