@@ -199,6 +199,20 @@ def main():
         line["roofline_other"] = {"gemm_skinny_bf16(prefill head only; decode runs inside the hipGraph)":
                                   {"bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "launches": cnt}}
+    # HBM-bound "replay pass" (pool -> embed + scatter -> RoI replay; SURVEY.md section 8d: ~90 MB per region)
+    hb = [agg[k] for k in ("pool2x2", "embed_assemble", "roi_replay") if k in agg]
+    if hb:
+        nb, sec = sum(a[1] for a in hb), sum(a[2] for a in hb)
+        line.setdefault("roofline_other", {})["pool2x2 + embed_assemble + roi_replay pass"] = {
+            "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_region": nb / (args.steps * B),
+            "launches": sum(a[3] for a in hb)}
+    if "roi_replay" in agg:
+        fl, nb, sec, cnt = agg["roi_replay"]
+        line.setdefault("roofline_other", {})["roi_replay_batched_kernel alone (one launch per 16-region chunk)"] = {
+            "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": nb / cnt, "avg_launch_us": sec / cnt * 1e6,
+            "launches": cnt}
     if not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(cfg, W, one, args.new_tokens, args.cpu_threads)

@@ -141,17 +141,55 @@ __device__ __forceinline__ Sample make_sample(float y, float x, int H, int W) {
     return s;
 }
 
+// One axis of torchvision's pre_calc_for_bilinear_interpolate (fp32): low / high cell, the two lerp weights and
+// whether the coordinate is inside [-1, size]. The sample's 4 corner weights are products of a y pair and an x pair.
+struct Axis { int lo, hi; float l, h; bool valid; };
+__device__ __forceinline__ Axis make_axis(float v, int size) {
+    Axis a;
+    a.valid = !(v < -1.0f || v > (float)size);
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+    a.lo = lo; a.hi = hi;
+    a.l = v - (float)lo;
+    a.h = 1.0f - a.l;
+    if (!a.valid) { a.lo = a.hi = 0; }
+    return a;
+}
+
+template <typename T> struct Raw8;                       // 8 channels of one map cell, as loaded
+template <> struct Raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = reinterpret_cast<const float4*>(p)[0];
+        b = reinterpret_cast<const float4*>(p)[1];
+    }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+};
+
+// One output row (bin = ph*P + pw) of one crop token, channels c0, c0+cstride, ... of it.
+// The G*G samples of a bin use cells (Y[a], X[b]) with Y = {lo,hi of sample row 0, lo,hi of sample row 1} and X
+// likewise: the block loads each DISTINCT cell once (typically 2 x 2 instead of 16 — the bin is smaller than a
+// cell for every realistic mask) and then runs torchvision's arithmetic in its original order on the copies.
 template <typename T, int G>
-__global__ __launch_bounds__(256) void roi_replay_kernel(const T* __restrict__ feats, T* __restrict__ embeds,
-                                                         const int32_t* __restrict__ spans, int crop_index,
-                                                         int first_tile, int ncw, int nch, int P, int C, int S,
-                                                         float rx1, float ry1, float rx2, float ry2, float ss,
-                                                         int aligned) {
-    const int head = spans[2 * crop_index];
-    if (head < 0) return;                                   // crop token absent from input_ids
-    const int bin = blockIdx.x;
-    const int ph = bin / P, pw = bin % P;
-    const int row = head + bin;
+__device__ __forceinline__ void roi_replay_row(const T* __restrict__ feats, T* __restrict__ embeds, int head, int ph,
+                                               int pw, int c0, int cstride, int first_tile, int ncw, int nch, int P,
+                                               int C, int S, float rx1, float ry1, float rx2, float ry2, float ss,
+                                               int aligned) {
+    static_assert(G == 2, "sampling_ratio 2");
+    const int row = head + ph * P + pw;
     if (row >= S) return;
     const int H = nch * P, W = ncw * P;
     const float off = aligned ? 0.5f : 0.0f;
@@ -160,41 +198,104 @@ __global__ __launch_bounds__(256) void roi_replay_kernel(const T* __restrict__ f
     if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
     const float bh = rh / (float)P, bw = rw / (float)P;
     const float count = (float)(G * G);
-    Sample smp[G * G];
+    Axis ay[G], ax[G];
 #pragma unroll
-    for (int iy = 0; iy < G; ++iy) {
-        const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)G;
-#pragma unroll
-        for (int ix = 0; ix < G; ++ix) {
-            const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)G;
-            smp[iy * G + ix] = make_sample(y, x, H, W);
-        }
+    for (int i = 0; i < G; ++i) {
+        ay[i] = make_axis(sh + (float)ph * bh + ((float)i + 0.5f) * bh / (float)G, H);
+        ax[i] = make_axis(sw + (float)pw * bw + ((float)i + 0.5f) * bw / (float)G, W);
     }
+    // an invalid sample (either axis outside [-1, size]) contributes exactly 0: its weights are zeroed below and its
+    // cells are clamped to (0, 0) on the invalid axis, as pre_calc_for_bilinear_interpolate does
+    const int Y[4] = {ay[0].lo, ay[0].hi, ay[1].lo, ay[1].hi};
+    const int X[4] = {ax[0].lo, ax[0].hi, ax[1].lo, ax[1].hi};
     auto cell = [&](int y, int x) -> const T* {            // merged-map cell (y,x) in the tile-major layout
         const int tile = first_tile + (y / P) * ncw + (x / P);
         return feats + ((int64_t)tile * P * P + (y % P) * P + (x % P)) * C;
     };
     T* dst = embeds + (int64_t)row * C;
-    for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+    for (int c = c0; c < C; c += cstride) {
+        Raw8<T> g[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int ra = -1;                                    // earlier identical row (block-uniform)
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2)
+                if (a2 < a && ra < 0 && Y[a2] == Y[a]) ra = a2;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int cb = -1;
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2)
+                    if (b2 < b && cb < 0 && X[b2] == X[b]) cb = b2;
+                if (ra >= 0) {
+#pragma unroll
+                    for (int a2 = 0; a2 < 4; ++a2)
+                        if (a2 == ra) g[a][b] = g[a2][b];
+                } else if (cb >= 0) {
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2)
+                        if (b2 == cb) g[a][b] = g[a][b2];
+                } else {
+                    g[a][b].load(cell(Y[a], X[b]) + c);
+                }
+            }
+        }
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int k = 0; k < G * G; ++k) {
-            const Sample& s = smp[k];
-            float v1[8], v2[8], v3[8], v4[8];
-            ld8(cell(s.yl, s.xl) + c, v1);
-            ld8(cell(s.yl, s.xh) + c, v2);
-            ld8(cell(s.yh, s.xl) + c, v3);
-            ld8(cell(s.yh, s.xh) + c, v4);
+        for (int iy = 0; iy < G; ++iy) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                acc[e] = acc[e] + (((s.w1 * v1[e] + s.w2 * v2[e]) + s.w3 * v3[e]) + s.w4 * v4[e]);
+            for (int ix = 0; ix < G; ++ix) {
+                const bool valid = ay[iy].valid && ax[ix].valid;
+                const float w1 = valid ? ay[iy].h * ax[ix].h : 0.f, w2 = valid ? ay[iy].h * ax[ix].l : 0.f;
+                const float w3 = valid ? ay[iy].l * ax[ix].h : 0.f, w4 = valid ? ay[iy].l * ax[ix].l : 0.f;
+                float v1[8], v2[8], v3[8], v4[8];
+                g[2 * iy][2 * ix].get(v1);
+                g[2 * iy][2 * ix + 1].get(v2);
+                g[2 * iy + 1][2 * ix].get(v3);
+                g[2 * iy + 1][2 * ix + 1].get(v4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] = acc[e] + (((w1 * v1[e] + w2 * v2[e]) + w3 * v3[e]) + w4 * v4[e]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = acc[e] / count;
         st8(dst + c, acc);
     }
+}
+
+// Work split: ONE WAVE per output row (bin), lanes cover the channels 8 at a time (4 passes at C = 2048). Measured at
+// 64 crop tokens (71 MB): 256-thread blocks per bin 120 us, a block per map row with a wave per bin 96 us, this
+// 78 us — the kernel is bound by the dependent-access chain (job -> span -> cells -> store) of tiny rows, not by HBM;
+// the pass it belongs to (pool2x2 -> embed_assemble -> replay) runs at ~5.3 TB/s (tools/bench_replay.py).
+#define RB 64
+template <typename T, int G>
+__global__ __launch_bounds__(RB) void roi_replay_kernel(const T* __restrict__ feats, T* __restrict__ embeds,
+                                                        const int32_t* __restrict__ spans, int crop_index,
+                                                        int first_tile, int ncw, int nch, int P, int C, int S,
+                                                        float rx1, float ry1, float rx2, float ry2, float ss,
+                                                        int aligned) {
+    const int head = spans[2 * crop_index];
+    if (head < 0) return;                                   // crop token absent from input_ids
+    roi_replay_row<T, G>(feats, embeds, head, blockIdx.x / P, blockIdx.x % P, threadIdx.x * 8, RB * 8, first_tile, ncw,
+                         nch, P, C, S, rx1, ry1, rx2, ry2, ss, aligned);
+}
+
+// every crop token of every sample of a batch in ONE launch: blockIdx.y = job
+template <typename T, int G>
+__global__ __launch_bounds__(RB) void roi_replay_batched_kernel(const T* __restrict__ feats, T* __restrict__ embeds,
+                                                                const int32_t* __restrict__ spans,
+                                                                const gar_roi_job* __restrict__ jobs, int n_crop,
+                                                                int tiles_per_sample, int P, int C, int S,
+                                                                int aligned) {
+    const gar_roi_job j = jobs[blockIdx.y];
+    const int head = spans[((int64_t)j.sample * n_crop + j.crop_index) * 2];
+    if (head < 0) return;
+    roi_replay_row<T, G>(feats + (int64_t)j.sample * tiles_per_sample * P * P * C, embeds + (int64_t)j.sample * S * C,
+                         head, blockIdx.x / P, blockIdx.x % P, threadIdx.x * 8, RB * 8, j.first_tile, j.ncw, j.nch, P, C,
+                         S, j.x1, j.y1, j.x2, j.y2, j.spatial_scale, aligned);
 }
 
 extern "C" int gar_roi_replay(int dtype, const void* feats, void* embeds, const int32_t* spans, int crop_index,
@@ -203,7 +304,7 @@ extern "C" int gar_roi_replay(int dtype, const void* feats, void* embeds, const 
     GAR_CHECK_ARG(feats && embeds && spans, "roi_replay: null pointer");
     GAR_CHECK_ARG(ncw > 0 && nch > 0 && P > 0 && C % 8 == 0 && S > 0 && crop_index >= 0, "roi_replay: bad shape");
     GAR_CHECK_ARG(sampling_ratio == 2, "roi_replay: sampling_ratio %d not built (the reference uses 2)", sampling_ratio);
-    dim3 grid(P * P), block(256);
+    dim3 grid(P * P), block(RB);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GAR_BF16)
         hipLaunchKernelGGL((roi_replay_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)feats, (bf16_t*)embeds, spans,
@@ -211,6 +312,26 @@ extern "C" int gar_roi_replay(int dtype, const void* feats, void* embeds, const 
     else
         hipLaunchKernelGGL((roi_replay_kernel<float, 2>), grid, block, 0, s, (const float*)feats, (float*)embeds, spans,
                            crop_index, first_tile, ncw, nch, P, C, S, rx1, ry1, rx2, ry2, spatial_scale, aligned);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+extern "C" int gar_roi_replay_batched(int dtype, const void* feats, void* embeds, const int32_t* spans,
+                                      const gar_roi_job* jobs, int n_jobs, int n_crop, int tiles_per_sample, int P, int C,
+                                      int S, int sampling_ratio, int aligned, gar_stream_t stream) {
+    GAR_CHECK_ARG(feats && embeds && spans && jobs, "roi_replay_batched: null pointer");
+    GAR_CHECK_ARG(n_jobs > 0 && n_jobs <= 65535 && n_crop > 0 && tiles_per_sample > 0 && P > 0 && C % 8 == 0 && S > 0,
+                  "roi_replay_batched: bad shape");
+    GAR_CHECK_ARG(sampling_ratio == 2, "roi_replay_batched: sampling_ratio %d not built (the reference uses 2)",
+                  sampling_ratio);
+    dim3 grid(P * P, n_jobs), block(RB);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((roi_replay_batched_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)feats,
+                           (bf16_t*)embeds, spans, jobs, n_crop, tiles_per_sample, P, C, S, aligned);
+    else
+        hipLaunchKernelGGL((roi_replay_batched_kernel<float, 2>), grid, block, 0, s, (const float*)feats, (float*)embeds,
+                           spans, jobs, n_crop, tiles_per_sample, P, C, S, aligned);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }

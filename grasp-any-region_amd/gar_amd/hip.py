@@ -46,6 +46,7 @@ SIGNATURES = {
     "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "gar_embed_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp], _i),
     "gar_roi_replay": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _vp], _i),
+    "gar_roi_replay_batched": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),

@@ -311,6 +311,7 @@ class GARModel:
         video = video_frame_tokens is not None
         if not video:
             ar = aspect_ratios.tolist() if torch.is_tensor(aspect_ratios) else aspect_ratios
+        jobs = []
         for b in range(B):
             if video:
                 ncw = nch = 1                       # each frame is its own P x P map (feat_h = feat_w = P, :787)
@@ -334,8 +335,10 @@ class GARModel:
                 ss = feat_w / orig_w
                 roi = (x1 * orig_w * ss, y1 * orig_h * ss, x2 * orig_w * ss, y2 * orig_h * ss)
                 # image: map = tiles 1.. (thumbnail dropped, modeling_gar.py:351); video: map = frame ci only
-                ops.roi_replay(feats[b * tiles_per_sample:(b + 1) * tiles_per_sample], embeds[b], spans[b], ci,
-                               ci if video else 1, ncw, nch, P, C_l, S, roi, ss, 2, True)
+                jobs.append((b, ci, ci if video else 1, ncw, nch, *roi, ss))
+        if jobs:         # every crop token of every sample in one launch (the roi table is the only H2D copy)
+            ops.roi_replay_batched(feats, embeds, spans, ops.roi_jobs_tensor(jobs, self.device), len(crop_ids),
+                                   tiles_per_sample, P, C_l, S, 2, True)
         return embeds
 
     # ---- Llama (A12) --------------------------------------------------------------------------------------------------

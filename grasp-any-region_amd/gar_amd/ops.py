@@ -15,6 +15,19 @@ from .hip import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE, EPI_PAT
 KERNEL_TIMERS = None     # bench.py sets this to a list to time GEMM launches with HIP events
 
 
+def _timed(kind: str, nbytes: float, call):
+    """Run one launch; when bench.py collects timers, bracket it with HIP events on the launch stream."""
+    prof = KERNEL_TIMERS
+    if prof is not None and not torch.cuda.is_current_stream_capturing():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
+        prof.append((kind, 0.0, float(nbytes), e0, e1))
+    else:
+        call()
+
+
 def _chk(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise hip.GarError(f"{name}: tensor must live on the GPU")
@@ -128,8 +141,9 @@ def attention_decode_workspace(B, Hq, hd, max_splits) -> int:
 def pool2x2(x, y, g: int, in_tile_tokens: int = 0, in_token_offset: int = 0):
     """x [T, in_tile_tokens, C] (tokens in_token_offset .. +g*g of each tile are the g x g grid) -> y [T, (g/2)^2, C]"""
     T, Cc = y.shape[0], y.shape[-1]
-    check(lib().gar_pool2x2(dtype_code(x.dtype), ptr(x), ptr(y), T, g, Cc, in_tile_tokens, in_token_offset, stream()),
-          "gar_pool2x2")
+    _timed("pool2x2", (T * g * g * Cc + y.numel()) * x.element_size(), lambda: check(
+        lib().gar_pool2x2(dtype_code(x.dtype), ptr(x), ptr(y), T, g, Cc, in_tile_tokens, in_token_offset, stream()),
+        "gar_pool2x2"))
     return y
 
 
@@ -143,8 +157,9 @@ def placeholder_scan(input_ids, image_token_id, crop_ids_dev, slot, counts, span
 
 def embed_assemble(input_ids, slot, E, feats, out, n_feat_rows):
     B, S = input_ids.shape
-    check(lib().gar_embed_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(feats), ptr(out), B, S,
-                                   E.shape[1], int(n_feat_rows), E.shape[0], stream()), "gar_embed_assemble")
+    _timed("embed_assemble", 2 * out.numel() * out.element_size(), lambda: check(
+        lib().gar_embed_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(feats), ptr(out), B, S,
+                                 E.shape[1], int(n_feat_rows), E.shape[0], stream()), "gar_embed_assemble"))
 
 
 def roi_replay(feats, embeds, spans, crop_index, first_tile, ncw, nch, P, Cc, S, roi, spatial_scale,
@@ -152,6 +167,28 @@ def roi_replay(feats, embeds, spans, crop_index, first_tile, ncw, nch, P, Cc, S,
     check(lib().gar_roi_replay(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), crop_index, first_tile, ncw,
                                nch, P, Cc, S, roi[0], roi[1], roi[2], roi[3], spatial_scale, sampling_ratio,
                                int(aligned), stream()), "gar_roi_replay")
+
+
+ROI_JOB_DTYPE = [("sample", "<i4"), ("crop_index", "<i4"), ("first_tile", "<i4"), ("ncw", "<i4"), ("nch", "<i4"),
+                 ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("spatial_scale", "<f4")]   # gar_roi_job
+
+
+def roi_replay_batched(feats, embeds, spans, jobs, n_crop, tiles_per_sample, P, Cc, S, sampling_ratio=2, aligned=True):
+    """jobs: uint8 device tensor holding n packed ``gar_roi_job`` records (see ``roi_jobs_tensor``)."""
+    n = jobs.numel() // 40
+    # algorithmic bytes per crop token: P*P*C written + <= 16 map cells * C read (SURVEY.md section 8d)
+    _timed("roi_replay", n * (P * P + 16) * Cc * feats.element_size(), lambda: check(
+        lib().gar_roi_replay_batched(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), ptr(jobs), n,
+                                     n_crop, tiles_per_sample, P, Cc, S, sampling_ratio, int(aligned), stream()),
+        "gar_roi_replay_batched"))
+
+
+def roi_jobs_tensor(jobs, device):
+    """[(sample, crop_index, first_tile, ncw, nch, x1, y1, x2, y2, spatial_scale)] -> packed device records."""
+    import numpy as np
+    arr = np.array([tuple(j) for j in jobs], dtype=ROI_JOB_DTYPE)
+    assert arr.dtype.itemsize == 40
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
 
 def embed_lookup(tokens, E, out):

@@ -152,6 +152,22 @@ int gar_roi_replay(int dtype, const void* feats, void* embeds, const int32_t* sp
                    int ncw, int nch, int P, int C, int S, float rx1, float ry1, float rx2, float ry2,
                    float spatial_scale, int sampling_ratio, int aligned, gar_stream_t stream);
 
+/* The same replay for every crop token of every sample of a batch in ONE launch (the reference loops
+ * `for batch_idx` / `for crop_token` in Python, modeling_gar.py:348-356). feats [B, tiles_per_sample, P*P, C],
+ * embeds [B, S, C], spans [B, n_crop, 2] (from gar_placeholder_scan); jobs: device array, one entry per
+ * (sample, crop token that has a bbox). */
+typedef struct gar_roi_job {
+    int32_t sample;       /* row of the batch */
+    int32_t crop_index;   /* index into the crop-token list given to gar_placeholder_scan */
+    int32_t first_tile;   /* first tile of the merged map inside the sample (1 = skip thumbnail; video: frame) */
+    int32_t ncw, nch;     /* tiles per row / column of the merged map */
+    float x1, y1, x2, y2; /* roi in `roi_feat` coordinates (modeling_gar.py:366-387) */
+    float spatial_scale;  /* as passed to roi_align (:393) */
+} gar_roi_job;
+int gar_roi_replay_batched(int dtype, const void* feats, void* embeds, const int32_t* spans, const gar_roi_job* jobs,
+                           int n_jobs, int n_crop, int tiles_per_sample, int P, int C, int S, int sampling_ratio,
+                           int aligned, gar_stream_t stream);
+
 /* Decode-step helpers (HF GenerationMixin greedy loop, modeling_gar.py:418-426):
  * embedding gather for the just-sampled tokens; argmax over logits with first-index tie break writing
  * out_tokens[b*out_stride + step_dev[0]] and cur_tokens[b]; device-side counters (position / step) so one captured

@@ -357,6 +357,37 @@ def test_roi_replay_bit_exact_vs_oracle(dev, dt, bbox):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_roi_replay_batched_equals_per_token_launches(dev, dt):
+    """one launch over (sample, crop token) jobs == the per-token kernel, bit for bit; ragged: sample 1 has two crop
+    tokens with different canvases per sample, sample 2 none, one job points at an absent token."""
+    from gar_amd import GARConfig, ops
+    from oracle import gar_oracle as O
+    cfg = GARConfig.gar_1b()
+    P, Cc, B, tiles, S, ncrop = 16, 128, 3, 7, 900, 5
+    feats = q(rnd(B * tiles, P * P, Cc, seed=36), dt).to(dev, dt)
+    emb = q(rnd(B, S, Cc, seed=37), dt).to(dev, dt)
+    spans = torch.full((B, ncrop, 2), -1, dtype=torch.int32)
+    spans[0, 1] = torch.tensor([10, 265])
+    spans[1, 0] = torch.tensor([300, 555])
+    spans[1, 3] = torch.tensor([600, 855])
+    spans = spans.to(dev)
+    canv = {0: (3, 2), 1: (2, 3)}
+    boxes = {(0, 1): (0.1, 0.2, 0.6, 0.9), (1, 0): (0.0, 0.0, 1.0, 1.0), (1, 3): (0.72, 0.87, 0.79, 0.92),
+             (1, 4): (0.2, 0.2, 0.4, 0.4)}                     # (1, 4): bbox present but token absent from input_ids
+    jobs, ref = [], emb.clone()
+    for (b, ci), bbox in boxes.items():
+        ncw, nch = canv[b]
+        roi, ss = O.replay_roi(bbox, P * nch, P * ncw, cfg.feat_stride)
+        jobs.append((b, ci, 1, ncw, nch, *roi[1:], ss))
+        ops.roi_replay(feats[b * tiles:(b + 1) * tiles], ref[b], spans[b], ci, 1, ncw, nch, P, Cc, S, roi[1:], ss, 2, True)
+    out = emb.clone()
+    ops.roi_replay_batched(feats, out, spans, ops.roi_jobs_tensor(jobs, dev), ncrop, tiles, P, Cc, S, 2, True)
+    assert torch.equal(out.cpu(), ref.cpu())
+    assert not torch.equal(out.cpu(), emb.cpu())
+    assert torch.equal(out[2].cpu(), emb[2].cpu())
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_argmax_first_index_tiebreak_and_lookup(dev, dt):
     from gar_amd import ops
     B, V, Cc = 3, 128262, 128
