@@ -196,121 +196,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const gar_gemm_params p, 
 }
 
 // ===============================================================================================================
-// skinny (M <= 16): weight streaming, split-K over the waves of a block
+// skinny f32 (M <= 16, parity mode): weight streaming, split-K over the waves of a block. The bf16 decode kernel
+// (M <= 64) lives in gemm_skinny.hip. NORM: fused RMSNorm prologue — the B operand is x*g (g = norm weight) and the
+// accumulator is scaled by rsqrt(mean(x^2)+eps) of its row in the epilogue (rstd factors out of the dot product).
 // ===============================================================================================================
-// bf16: per 64-wide K step lane (row = l&15, g = l>>4) reads W[row][k0+16g .. +16) as two adjacent 16-B loads (the four
-// g's of a row cover one 128-B line) and x[b = l&15][same k]; MFMA t uses the t-th 8-element half on both operands.
-// NORM: fused RMSNorm prologue — the B operand is x*g (g = norm weight) and the accumulator is scaled by
-// rsqrt(mean(x^2)+eps) of its row in the epilogue (rstd factors out of the dot product), so the decode step needs no
-// separate norm launch.
-template <int EPI, int NT, bool NORM>
-__global__ __launch_bounds__(1024) void skinny_bf16_kernel(const gar_gemm_params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);                  // [nw][NT][64][4] then [nw][16] sums of squares
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16 * NT;
-    const bf16_t* W = (const bf16_t*)p.W;
-    const bf16_t* X = (const bf16_t*)p.A;
-    const bf16_t* Gw = (const bf16_t*)p.norm_w;
-    const int ksteps = p.K / 64;
-    const int per = (ksteps + nw - 1) / nw;
-    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
-    const bool xvalid = frow < p.M;
-    const bf16_t* xp = X + (int64_t)(xvalid ? frow : 0) * p.lda + fq * 16;
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)min(n0 + t * 16 + frow, p.N - 1) * p.ldw + fq * 16;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ssq = 0.f;
-    auto step = [&](int ks) {
-        const int k0 = ks * 64;
-        bf16x8 w0[NT], w1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            w0[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k0));
-            w1[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k0 + 8));
-        }
-        bf16x8 x0, x1;
-        if (NORM) {
-            float xa[8], xb[8], ga[8], gb[8];
-            ld8(xp + k0, xa);
-            ld8(xp + k0 + 8, xb);
-            ld8(Gw + fq * 16 + k0, ga);
-            ld8(Gw + fq * 16 + k0 + 8, gb);
-            u32x4 pa, pb;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                ssq += xa[e] * xa[e] + xa[e + 1] * xa[e + 1] + xb[e] * xb[e] + xb[e + 1] * xb[e + 1];
-                pa[e >> 1] = pack_bf2(xa[e] * ga[e], xa[e + 1] * ga[e + 1]);
-                pb[e >> 1] = pack_bf2(xb[e] * gb[e], xb[e + 1] * gb[e + 1]);
-            }
-            x0 = __builtin_bit_cast(bf16x8, pa);
-            x1 = __builtin_bit_cast(bf16x8, pb);
-        } else {
-            x0 = *reinterpret_cast<const bf16x8*>(xp + k0);
-            x1 = *reinterpret_cast<const bf16x8*>(xp + k0 + 8);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[t], x0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t], x1, acc[t], 0, 0, 0);
-        }
-    };
-    int ks = ks0;
-    for (; ks + 4 <= ks1; ks += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) step(ks + u);
-    }
-    for (; ks < ks1; ++ks) step(ks);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        *reinterpret_cast<f32x4*>(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
-    float* red_ss = red + nw * NT * 256;
-    if (NORM) {
-        ssq += __shfl_xor(ssq, 16, 64);
-        ssq += __shfl_xor(ssq, 32, 64);
-        if (lane < 16) red_ss[wave * 16 + lane] = ssq;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    float v[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[t][r] = 0.f;
-        for (int w = 0; w < nw; ++w) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(red + ((w * NT + t) * 64 + lane) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[t][r] += a[r];
-        }
-    }
-    if (NORM) {
-        float tot = 0.f;
-        for (int w = 0; w < nw; ++w) tot += red_ss[w * 16 + frow];
-        const float rstd = rsqrtf(tot / (float)p.K + p.norm_eps);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
-    }
-    if (!xvalid) return;
-    if (EPI == GAR_EPI_SWIGLU) {
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = silu(v[0][r]) * v[NT - 1][r];
-        epilogue_store<bf16_t, EPI>(p, frow, (n0 >> 1) + fq * 4, o);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t * 16 + fq * 4;
-            if (n < p.N) epilogue_store<bf16_t, EPI>(p, frow, n, v[t]);
-        }
-    }
-}
-
 // f32: lane reads float4 W[row][k0+4g..+4), x likewise; MFMA t (16x16x4) consumes element t of both.
 template <int EPI, int NT, bool NORM>
 __global__ __launch_bounds__(1024) void skinny_f32_kernel(const gar_gemm_params p) {
@@ -411,21 +300,13 @@ static int pick_waves(int n_blocks, int ksteps) {
 template <int EPI>
 static int launch(int dtype, const gar_gemm_params& p, hipStream_t s) {
     if (dtype == GAR_BF16 && p.M <= 64 && gar_skinny_bf16_try(p, s)) return GAR_OK;   // gemm_skinny.hip
-    if (p.M <= 16) {
+    if (dtype == GAR_F32 && p.M <= 16) {
         constexpr int NT = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
         const int nb = (p.N + 16 * NT - 1) / (16 * NT);
-        const bool norm = p.norm_w != nullptr;
-        if (dtype == GAR_BF16) {
-            const int nw = pick_waves(nb, p.K / 64);
-            const int lds = nw * NT * 1024 + nw * 64;
-            if (norm) hipLaunchKernelGGL((skinny_bf16_kernel<EPI, NT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
-            else hipLaunchKernelGGL((skinny_bf16_kernel<EPI, NT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
-        } else {
-            const int nw = pick_waves(nb, p.K / 16);
-            const int lds = nw * NT * 1024 + nw * 64;
-            if (norm) hipLaunchKernelGGL((skinny_f32_kernel<EPI, NT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
-            else hipLaunchKernelGGL((skinny_f32_kernel<EPI, NT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
-        }
+        const int nw = pick_waves(nb, p.K / 16);
+        const int lds = nw * NT * 1024 + nw * 64;
+        if (p.norm_w) hipLaunchKernelGGL((skinny_f32_kernel<EPI, NT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
+        else hipLaunchKernelGGL((skinny_f32_kernel<EPI, NT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
         return GAR_OK;
     }
     if (dtype == GAR_BF16) {
@@ -458,7 +339,8 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
     if (e == GAR_EPI_SWIGLU) GAR_CHECK_ARG(p.N % 32 == 0, "gar_gemm: SWIGLU needs N%%32==0");
     if (p.norm_w)
         GAR_CHECK_ARG(p.M <= (dtype == GAR_BF16 ? 64 : 16) &&
-                          (e == GAR_EPI_NONE || e == GAR_EPI_RES || e == GAR_EPI_SWIGLU || e == GAR_EPI_BIAS),
+                          (e == GAR_EPI_NONE || e == GAR_EPI_RES || e == GAR_EPI_SWIGLU ||
+                           (e == GAR_EPI_BIAS && dtype == GAR_BF16) || dtype == GAR_F32),
                       "gar_gemm: fused RMSNorm prologue is built for the decode path only (M <= 64 bf16 / 16 f32)");
     if (e == GAR_EPI_PATCH_POS)
         GAR_CHECK_ARG(p.pos && p.tokens_in > 0 && p.tokens_out >= p.tokens_in + p.token_offset && p.N % 4 == 0,

@@ -8,13 +8,18 @@
 //
 //   K tile = 4 phases: (A0,B0) (B1) (A1) (B0)     A0/A1 = m-tiles 0-3 / 4-7 of the wave, B0/B1 = n-tiles 0-1 / 2-3
 //   staging: the next K tile (of this output tile, or K tile 0 of the NEXT output tile of the persistent loop) is
-//     DMA'd with global_load_lds (lane-linear LDS image, XOR swizzle applied to the SOURCE address) into the other
-//     stage during phase 0 (both A halves) and phase 1 (both W halves) — >= 2 intervals after the last ds_read of
-//     that stage (WAR) — and waited for with vmcnt(0) right before the last barrier of the K tile that both rows
-//     share, ~5 intervals after issue (RAW). Because the next output tile's first K tile is already in LDS when the
-//     epilogue starts, the epilogue's stores drain into L2/HBM underneath the next tile's main loop.
+//     DMA'd with `buffer_load_dwordx4 ... lds` (lane-linear LDS image, XOR swizzle applied to the SOURCE address,
+//     M / N tails zero-filled by the descriptor's bounds check) into the other stage during phase 0 (both A halves)
+//     and phase 1 (both W halves) — >= 2 intervals after the last ds_read of that stage (WAR) — and waited for with
+//     vmcnt(0) right before the last barrier of the K tile that both rows share, ~5 intervals after issue (RAW).
+//     The next output tile's first K tile is already in LDS when the epilogue starts.
 //   epilogue: the W rows of an n-tile pair are fed in a permuted order so that a lane ends up with EIGHT consecutive
-//     output columns: bias / LayerScale / residual loads and the store are 16-byte vectors (64-B segments per row).
+//     output columns; the fp32 accumulators go through the just-consumed LDS stage in four 64-row chunks and are read
+//     back row-wise, so bias / LayerScale / residual loads and the stores are 16-byte vectors covering 512
+//     contiguous bytes per row (SwiGLU and the PERM=0 variant store straight from the fragments).
+//   Measured limits (profiles/README.md): main loop 1.3-1.4 PFLOP/s; the epilogue is exposed
+//     (store issue back-pressures at ~0.4 TB/s of L2 write-back per XCD and gfx9's in-order vmcnt ties the next
+//     tile's DMA waits to the outstanding stores).
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"

@@ -414,7 +414,7 @@ class GARModel:
         q_scale = (hd ** -0.5) * LOG2E
         pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
         # enough (split, kv head, batch) 4-wave blocks to cover the chip: ~512 blocks = 2048 waves
-        nsplit = max(1, min(64, 512 // max(1, B * Hkv)))
+        nsplit = max(1, min(64, int(os.environ.get("GAR_DECODE_BLOCKS", "512")) // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
         fuse = B <= 16     # RMSNorm folded into the skinny GEMM prologue (every block redoes x*g: only pays for <= 16 rows)
