@@ -8,6 +8,8 @@
 //   half of both. NORM: x*g is the operand and rsqrt(mean(x^2)+eps) scales the accumulator row in the epilogue.
 //   The waves' partial accumulators are merged in LDS, row tile mt by wave (mt mod nw).
 //   Algorithmic bytes per launch = N*K*2 (weights) + small.
+#include <stdlib.h>
+
 #include "gemm_epilogue.h"
 
 template <int EPI, int NT, int MT, bool NORM>
@@ -130,11 +132,14 @@ __global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_par
                 for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
         }
         if (m >= p.M) continue;
-        if (EPI == GAR_EPI_SWIGLU) {
-            float o[4];
+        if (EPI == GAR_EPI_SWIGLU) {          // weight tiles come in (gate16, up16) pairs
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = silu(v[0][r]) * v[NT - 1][r];
-            epilogue_store<bf16_t, EPI>(p, m, (n0 >> 1) + fq * 4, o);
+            for (int q = 0; q < NT / 2; ++q) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(v[2 * q][r]) * v[2 * q + 1][r];
+                if (n0 + q * 32 < p.N) epilogue_store<bf16_t, EPI>(p, m, (n0 >> 1) + q * 16 + fq * 4, o);
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -145,27 +150,46 @@ __global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_par
     }
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int NT>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
-    constexpr int NT = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
     const int nb = (p.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = p.K / 64;
-    // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, reduction buffer <= 64 KiB
+    // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, reduction buffer <= 136 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        if constexpr (NT <= 2)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
+        attr_set = true;
+    }
     int nw = 4;
-    while (nw < 16 && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && (nw * 2) * NT * MT * 1024 + (nw * 2) * MT * 64 <= 65536)
+    while (nw < 16 && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && (nw * 2) * NT * MT * 1024 + (nw * 2) * MT * 64 <= 139264)
         nw *= 2;
     const int lds = nw * NT * MT * 1024 + nw * MT * 64;
-    if (p.norm_w)
-        hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
-    else
-        hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
+    if constexpr (NT <= 2) {
+        if (p.norm_w) {
+            hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
 }
 
+// NT = weight tiles (16 rows) per block. With several row tiles (M > 16) every block re-reads the activations from
+// L2, MT x the bytes of its weight tile: wide outputs (gate/up, lm_head) use 4 weight tiles per block so one activation
+// fragment serves 4 of them; narrow outputs keep 1 (2 for SwiGLU pairs) for the sake of block count.
 template <int EPI>
 static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
-    if (p.M <= 16) launch_skinny<EPI, 1>(p, s);
-    else if (p.M <= 32) launch_skinny<EPI, 2>(p, s);
-    else launch_skinny<EPI, 4>(p, s);
+    constexpr int NT0 = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
+    static const int wide = [] { const char* e = getenv("GAR_SKINNY_WIDE_N"); return e ? atoi(e) : 8192; }();
+    if (p.M <= 16) launch_skinny<EPI, 1, NT0>(p, s);
+    else if (p.M <= 32) {
+        if (p.N >= wide && !p.norm_w) launch_skinny<EPI, 2, 4>(p, s); else launch_skinny<EPI, 2, NT0>(p, s);
+    } else {
+        if (p.N >= wide && !p.norm_w) launch_skinny<EPI, 4, 4>(p, s); else launch_skinny<EPI, 4, NT0>(p, s);
+    }
 }
 
 // bf16, M <= 64, the epilogues the decode step uses. Returns false otherwise.

@@ -463,6 +463,18 @@ def test_skinny_gemm_batched_rows_bf16(dev, M):
     o2 = torch.empty(M, Fd, dtype=dt, device=dev)
     ops.gemm(x.to(dev, dt), gu.to(dev, dt), o2, hip.EPI_SWIGLU, norm_w=g.to(dev, dt), norm_eps=1e-5)
     close(o2, F.silu(nrm @ gw.double().T) * (nrm @ uw.double().T), dt, extra=2.0)
+    # wide outputs (gate/up, lm_head) take 4 weight tiles per block; N with a ragged last block
+    Nw = 8192 + 48
+    ww = q(rnd(Nw, K, seed=64, scale=K ** -0.5), dt)
+    ow = torch.empty(M, Nw, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), ww.to(dev, dt), ow)
+    close(ow, xd @ ww.double().T, dt)
+    Fw = 4096 + 16
+    gw2, uw2 = ww[:Fw], ww[Fw:2 * Fw]
+    gu2 = torch.stack([gw2.view(Fw // 16, 16, K), uw2.view(Fw // 16, 16, K)], 1).reshape(2 * Fw, K)
+    o3 = torch.empty(M, Fw, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), gu2.to(dev, dt), o3, hip.EPI_SWIGLU)
+    close(o3, F.silu(xd @ gw2.double().T) * (xd @ uw2.double().T), dt)
     # a row's result does not depend on the batch it rides in (up to the split-K summation order)
     o1 = torch.empty(1, N, dtype=dt, device=dev)
     ops.gemm(x[M - 1:M].to(dev, dt).contiguous(), w.to(dev, dt), o1)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the decode (skinny, M <= 64) bf16 GEMMs on GAR-1B's decode shapes: 32 back-to-back launches
+captured in one hipGraph, HIP-event timed; reports us per launch and the weight-stream rate."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grasp-any-region_amd"))
+import torch  # noqa: E402
+
+from gar_amd import hip, ops  # noqa: E402
+
+SHAPES = [("qkv", 3072, 2048, hip.EPI_NONE), ("o", 2048, 2048, hip.EPI_RES), ("gate/up", 16384, 2048, hip.EPI_SWIGLU),
+          ("down", 2048, 8192, hip.EPI_RES), ("lm_head", 128262, 2048, hip.EPI_NONE)]
+
+
+def main():
+    hip.require_device(0)
+    dev = "cuda:0"
+    L = 16
+    for M in (int(a) for a in (sys.argv[1:] or ["16", "64"])):
+        tot = 0.0
+        for name, N, K, epi in SHAPES:
+            # L distinct weight matrices so the stream comes from HBM, not from the Infinity Cache
+            ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(L if N < 100000 else 2)]
+            a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+            out = torch.zeros(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
+            kw = {"residual": out} if epi == hip.EPI_RES else {}
+
+            def run():
+                for w in ws:
+                    ops.gemm(a, w, out, epi, **kw)
+            run()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 5 / len(ws) * 1e3
+            nb = N * K * 2
+            per_step = us * (16 if N < 100000 else 1)
+            tot += per_step
+            print(f"M={M:3d} {name:8s} N={N:6d} K={K:5d}  {us:8.1f} us  {nb / us / 1e6:7.2f} TB/s", flush=True)
+        print(f"M={M:3d} GEMMs of one decode step (16 layers + head): {tot / 1e3:.3f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
