@@ -47,6 +47,9 @@ SIGNATURES = {
     "gar_embed_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp], _i),
     "gar_roi_replay": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _vp], _i),
     "gar_roi_replay_batched": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "gar_resize_bicubic_h": ([_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
+    "gar_resize_bicubic_v_tiles": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _vp], _i),
+    "gar_resize_nearest_tiles": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp], _i),
     "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),

@@ -191,6 +191,24 @@ def roi_jobs_tensor(jobs, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
 
+def resize_bicubic_tiles(src_u8, tmp, out, ts, ncw, tile0, xt, yt, mean, std):
+    """src_u8 [H,W,3] uint8 (device) -> normalised tiles written into out [tiles,3,ts,ts]; xt / yt = (first, count,
+    weights[n_out,kmax]) device tap tables of the two passes; tmp: fp32 scratch of >= 3*H*Wout elements."""
+    H, W, _ = src_u8.shape
+    Wout, Hout = xt[2].shape[0], yt[2].shape[0]
+    check(lib().gar_resize_bicubic_h(ptr(src_u8), ptr(tmp), H, W, Wout, ptr(xt[0]), ptr(xt[1]), ptr(xt[2]),
+                                     xt[2].shape[1], stream()), "gar_resize_bicubic_h")
+    check(lib().gar_resize_bicubic_v_tiles(dtype_code(out.dtype), ptr(tmp), ptr(out), H, Wout, Hout, ts, ncw, tile0,
+                                           ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), yt[2].shape[1], mean, std, stream()),
+          "gar_resize_bicubic_v_tiles")
+
+
+def resize_nearest_tiles(src_u8, out, ts, ncw, tile0, xi, yi, mean, std):
+    H, W, _ = src_u8.shape
+    check(lib().gar_resize_nearest_tiles(dtype_code(out.dtype), ptr(src_u8), ptr(out), H, W, yi.numel(), xi.numel(), ts,
+                                         ncw, tile0, ptr(xi), ptr(yi), mean, std, stream()), "gar_resize_nearest_tiles")
+
+
 def embed_lookup(tokens, E, out):
     check(lib().gar_embed_lookup(dtype_code(E.dtype), ptr(tokens), ptr(E), ptr(out), tokens.numel(), E.shape[1],
                                  E.shape[0], stream()), "gar_embed_lookup")

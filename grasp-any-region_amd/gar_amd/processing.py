@@ -276,6 +276,14 @@ class GARProcessor:
             tokenizer = StubTokenizer() if cfg.mllm_config.image_token_id == 128002 else StubTokenizer.tiny()
         return cls(tokenizer, v.img_size, max_num_tiles, v.patch_size, cfg.mllm_config.projector_pooling_ratio)
 
+    def use_gpu_preprocessing(self, device="cuda:0", dtype: torch.dtype = torch.bfloat16):
+        """Swap the host image processor for the device one (``preprocess_gpu.GpuImageProcessor``): same contract,
+        ``pixel_values`` / ``mask_values`` come back as device tensors in ``dtype``. Returns self."""
+        from .preprocess_gpu import GpuImageProcessor
+        ip = self.image_processor
+        self.image_processor = GpuImageProcessor(ip.tile_size, ip.max_num_tiles, "bicubic", device, dtype)
+        return self
+
     @classmethod
     def from_pretrained(cls, path: str, cfg=None, max_num_tiles: int = 16):
         import os

@@ -168,6 +168,22 @@ int gar_roi_replay_batched(int dtype, const void* feats, void* embeds, const int
                            int n_jobs, int n_crop, int tiles_per_sample, int P, int C, int S, int sampling_ratio,
                            int aligned, gar_stream_t stream);
 
+/* GPU-side preprocessing (PerceptionLMImageProcessorFast.resize -> _split -> rescale_and_normalize,
+ * image_processing_perception_lm_fast.py:268-372; NEAREST for the visual-prompt id matrix, eval_dataset.py:122-139).
+ * src: uint8 RGB image [H, W, 3] on the device. Separable antialiased bicubic: pass 1 (horizontal) writes fp32
+ * tmp [3, H, Wout]; pass 2 (vertical) rounds half-to-even, clamps to [0,255], normalises ((v/255)-mean)/std and
+ * writes tiles out[tile0 + (yo/ts)*ncw + (xo/ts)][c][yo%ts][xo%ts] in `dtype`. Tap tables (first source index,
+ * tap count, weights [n_out, kmax]) come from the host. Accumulation order: t = s[0]*w[0]; t = fma(s[j], w[j], t). */
+int gar_resize_bicubic_h(const uint8_t* src, float* tmp, int H, int W, int Wout, const int32_t* xmin,
+                         const int32_t* xsize, const float* wx, int kmax, gar_stream_t stream);
+int gar_resize_bicubic_v_tiles(int dtype, const float* tmp, void* out, int H, int Wout, int Hout, int ts, int ncw,
+                               int tile0, const int32_t* ymin, const int32_t* ysize, const float* wy, int kmax,
+                               float mean, float stdv, gar_stream_t stream);
+/* nearest: out pixel (yo, xo) = src[yi[yo]][xi[xo]] (index tables from the host), same normalisation and tiling */
+int gar_resize_nearest_tiles(int dtype, const uint8_t* src, void* out, int H, int W, int Hout, int Wout, int ts,
+                             int ncw, int tile0, const int32_t* xi, const int32_t* yi, float mean, float stdv,
+                             gar_stream_t stream);
+
 /* Decode-step helpers (HF GenerationMixin greedy loop, modeling_gar.py:418-426):
  * embedding gather for the just-sampled tokens; argmax over logits with first-index tie break writing
  * out_tokens[b*out_stride + step_dev[0]] and cur_tokens[b]; device-side counters (position / step) so one captured

@@ -152,3 +152,30 @@ def test_weights_naming_and_io(tmp_path):
         check_weights(cfg, W2)
     n1b = sum(int(np.prod(s)) for s in weight_shapes(GARConfig.gar_1b()).values())
     assert 1.5e9 < n1b < 1.6e9
+
+
+def test_resampling_tables_for_gpu_preprocessing():
+    """tap tables used by the device preprocessing: weights reproduce torch's antialiased bicubic exactly (a resize
+    done with the tables in numpy, sequential fma order, equals F.interpolate), NEAREST indices = floor(i * in/out)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from gar_amd.preprocess_gpu import bicubic_aa_taps, nearest_index
+    rng = np.random.default_rng(0)
+    for n_in, n_out in [(53, 24), (48, 96), (100, 64)]:
+        first, count, w = bicubic_aa_taps(n_in, n_out)
+        assert np.allclose(w.sum(1), 1.0, atol=1e-5) and (count > 0).all() and (first + count <= n_in).all()
+        x = rng.integers(0, 256, (5, n_in)).astype(np.float32)
+        ref = F.interpolate(torch.from_numpy(x).reshape(1, 1, 5, n_in), size=(5, n_out), mode="bicubic",
+                            align_corners=False, antialias=True)[0, 0].numpy()
+        out = np.zeros((5, n_out), np.float32)
+        for i in range(n_out):
+            t = (x[:, first[i]] * w[i, 0]).astype(np.float32)
+            for j in range(1, count[i]):
+                t = (x[:, first[i] + j].astype(np.float64) * np.float64(w[i, j]) + t.astype(np.float64)).astype(np.float32)
+            out[:, i] = t
+        assert np.abs(out - ref).max() <= 1e-4          # exact on FMA hosts; unfused hosts differ in the last bits
+    for n_in, n_out in [(1024, 1792), (770, 448), (5, 448)]:
+        idx = nearest_index(n_in, n_out)
+        scale = np.float32(n_in) / np.float32(n_out)
+        exp = np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int32), n_in - 1)
+        assert np.array_equal(idx, exp)
