@@ -24,6 +24,8 @@ def base_parser(description):
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--max_num_tiles", type=int, default=16)
     ap.add_argument("--max_new_tokens", type=int, default=1024)
+    ap.add_argument("--host_preprocessing", action="store_true",
+                    help="resize / tile / normalise on the CPU (torch bicubic) instead of the device kernels")
     ap.add_argument("--synthetic_weights", action="store_true",
                     help="seeded random weights of the named size + the stub tokenizer (plumbing / benchmarking)")
     return ap
@@ -43,6 +45,8 @@ def load(args):
     else:
         model = GARModel.from_pretrained(args.model_name_or_path, dtype, args.device)
         processor = GARProcessor.from_pretrained(args.model_name_or_path, model.config, args.max_num_tiles)
+    if not args.host_preprocessing:
+        processor.use_gpu_preprocessing(args.device, dtype)
     return model.eval(), processor, dtype
 
 
