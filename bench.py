@@ -264,7 +264,7 @@ def main():
             "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": nb / cnt, "avg_launch_us": sec / cnt * 1e6,
             "launches": cnt}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
         try:
             line["cpu_baseline"] = cpu_baseline(cfg, W, one, args.new_tokens, args.cpu_threads)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result

@@ -317,3 +317,26 @@ def test_f32_video_replay_gar8b_structure_tiny():
     assert out.sequences.cpu().tolist() == ref_seq.tolist()
     err = float((out.logits.cpu() - ref_logits).abs().max())
     assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
+
+
+def test_replica_from_shapes_after_weight_copy(tiny):
+    """the non-source ranks of the data-parallel runner build the model from shapes only and receive the PREPARED weight
+    tensors by RCCL broadcast (bench.py): emulate the broadcast with copies and require identical captions — also for
+    the GAR-8B-like structure, whose prepared tensors are padded / untied."""
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    for cfg in (tiny[0], _tiny_8b_like()):
+        W = synthetic_weights(cfg)
+        proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+        s = _sample(cfg, proc, 4, dtype=torch.bfloat16)
+        src = GARModel(cfg, W, torch.bfloat16)
+        dst = GARModel.from_shapes(cfg, torch.bfloat16)
+        a, b = src.weight_tensors(), dst.weight_tensors()
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and x.dtype == y.dtype
+            y.copy_(x)
+        o0 = src.generate(**s, max_new_tokens=6, return_logits=True)
+        o1 = dst.generate(**s, max_new_tokens=6, return_logits=True)
+        assert torch.equal(o0.sequences, o1.sequences) and torch.equal(o0.logits, o1.logits)
