@@ -12,8 +12,15 @@
 
 #include "gemm_epilogue.h"
 
-template <int EPI, int NT, int MT, bool NORM>
-__global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+
+// STAGED: every wave brings the [16 x 64] bf16 tiles of a K step (NT weight tiles + MT activation tiles, 2 KiB each)
+// into a private LDS region with `buffer_load_dwordx4 ... lds` — whole 128-byte row segments, 8 rows per instruction —
+// and reads MFMA fragments back with conflict-free ds_read_b128 (chunk ^= (row >> 1) & 7, applied on the DMA source
+// side). Per-lane fragment loads from global memory touch 16 lines (half used) per instruction; for M = 64 the four
+// activation tiles re-read from L2 that way cost more than the weight stream itself (tools/bench_skinny.py).
+template <int EPI, int NT, int MT, bool NORM, bool STAGED>
+__global__ __launch_bounds__(NT >= 4 ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,6 +52,87 @@ __global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_par
     float ssq[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) ssq[mt] = 0.f;
+
+    // ---- STAGED path: DMA tiles -> LDS -> fragments
+    constexpr int REG = (NT + MT) * 2048;
+    char* wreg = smem + wave * REG;
+    const unsigned rbW = (unsigned)p.ldw * 2u, rbX = (unsigned)p.lda * 2u;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)X, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    int voffW[2], voffX[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const int c = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        voffW[i] = (int)((unsigned)(n0 + row) * rbW) + c;
+        voffX[i] = (int)((unsigned)row * rbX) + c;
+    }
+    auto stage = [&](int ks) {
+        const unsigned k0b = (unsigned)ks * 128u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(wreg + t * 2048 + i * 1024), 16,
+                                                         voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_AS(wreg + (NT + mt) * 2048 + i * 1024), 16,
+                                                         voffX[i] + (int)((unsigned)(mt * 16) * rbX + k0b), 0, 0, 0);
+    };
+    const int foff0 = frow * 128 + (((2 * fq) ^ ((frow >> 1) & 7)) << 4);
+    const int foff1 = frow * 128 + (((2 * fq + 1) ^ ((frow >> 1) & 7)) << 4);
+    auto step_staged = [&](int ks, bool more) {
+        const int k0 = ks * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8 w0[NT], w1[NT], xr0[MT], xr1[MT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            w0[t] = *reinterpret_cast<const bf16x8*>(wreg + t * 2048 + foff0);
+            w1[t] = *reinterpret_cast<const bf16x8*>(wreg + t * 2048 + foff1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            xr0[mt] = *reinterpret_cast<const bf16x8*>(wreg + (NT + mt) * 2048 + foff0);
+            xr1[mt] = *reinterpret_cast<const bf16x8*>(wreg + (NT + mt) * 2048 + foff1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage(ks + 1);                 // re-arm the region: its fragments are in registers now
+        __builtin_amdgcn_sched_barrier(0);
+        float ga[8], gb[8];
+        if (NORM) {
+            ld8(Gw + fq * 16 + k0, ga);
+            ld8(Gw + fq * 16 + k0 + 8, gb);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 x0 = xr0[mt], x1 = xr1[mt];
+            if (NORM) {
+                const u32x4 ua = __builtin_bit_cast(u32x4, x0), ub = __builtin_bit_cast(u32x4, x1);
+                u32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = __uint_as_float(ua[e] << 16), a1 = __uint_as_float(ua[e] & 0xffff0000u);
+                    const float b0 = __uint_as_float(ub[e] << 16), b1 = __uint_as_float(ub[e] & 0xffff0000u);
+                    ssq[mt] += a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1;
+                    pa[e] = pack_bf2(a0 * ga[2 * e], a1 * ga[2 * e + 1]);
+                    pb[e] = pack_bf2(b0 * gb[2 * e], b1 * gb[2 * e + 1]);
+                }
+                x0 = __builtin_bit_cast(bf16x8, pa);
+                x1 = __builtin_bit_cast(bf16x8, pb);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[t], x0, acc[t][mt], 0, 0, 0);
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t], x1, acc[t][mt], 0, 0, 0);
+            }
+        }
+    };
 
     auto step = [&](int ks) {
         const int k0 = ks * 64;
@@ -87,11 +175,17 @@ __global__ __launch_bounds__(1024) void skinny_mt_bf16_kernel(const gar_gemm_par
         }
     };
     int ks = ks0;
-    for (; ks + 2 <= ks1; ks += 2) {
-        step(ks);
-        step(ks + 1);
+    if (STAGED) {
+        if (ks < ks1) stage(ks);
+        for (; ks < ks1; ++ks) step_staged(ks, ks + 1 < ks1);
+        __syncthreads();                          // the merge buffer below aliases the staging regions
+    } else {
+        for (; ks + 2 <= ks1; ks += 2) {
+            step(ks);
+            step(ks + 1);
+        }
+        for (; ks < ks1; ++ks) step(ks);
     }
-    for (; ks < ks1; ++ks) step(ks);
 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -154,27 +248,46 @@ template <int EPI, int MT, int NT>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     const int nb = (p.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = p.K / 64;
-    // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, reduction buffer <= 136 KiB
+    static const int staged_mode = [] { const char* e = getenv("GAR_SKINNY_LDS"); return e ? atoi(e) : 1; }();
+    // buffer descriptors address W / x with 32-bit byte offsets
+    const bool staged = staged_mode && ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) &&
+                        ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
+    constexpr int MAXLDS = 139264;
     static bool attr_set = false;
     if (!attr_set) {
-        if constexpr (NT <= 2)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
+        if constexpr (NT <= 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
         attr_set = true;
     }
+    // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, LDS (merge buffer, and the
+    // per-wave staging regions it aliases) <= 136 KiB
+    auto lds_for = [&](int w) {
+        const int merge = w * NT * MT * 1024 + w * MT * 64;
+        const int stg = staged ? w * (NT + MT) * 2048 : 0;
+        return merge > stg ? merge : stg;
+    };
     int nw = 4;
-    while (nw < 16 && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && (nw * 2) * NT * MT * 1024 + (nw * 2) * MT * 64 <= 139264)
-        nw *= 2;
-    const int lds = nw * NT * MT * 1024 + nw * MT * 64;
+    const int max_nw = NT >= 4 ? 8 : 16;                 // 4-tile blocks are built for <= 512 threads (256 VGPRs)
+    while (nw < max_nw && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && lds_for(nw * 2) <= MAXLDS) nw *= 2;
+    const int lds = lds_for(nw);
+#define LAUNCH_SK(NORM_, ST_) \
+    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_>), dim3(nb), dim3(nw * 64), lds, s, p)
     if constexpr (NT <= 2) {
         if (p.norm_w) {
-            hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, true>), dim3(nb), dim3(nw * 64), lds, s, p);
+            if (staged) LAUNCH_SK(true, true); else LAUNCH_SK(true, false);
             return;
         }
     }
-    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, false>), dim3(nb), dim3(nw * 64), lds, s, p);
+    if (staged) LAUNCH_SK(false, true); else LAUNCH_SK(false, false);
+#undef LAUNCH_SK
 }
 
 // NT = weight tiles (16 rows) per block. With several row tiles (M > 16) every block re-reads the activations from
