@@ -417,7 +417,7 @@ class GARModel:
         nsplit = max(1, min(64, int(os.environ.get("GAR_DECODE_BLOCKS", "512")) // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
-        fuse = B <= 16     # RMSNorm folded into the skinny GEMM prologue (every block redoes x*g: only pays for <= 16 rows)
+        fuse = B <= int(os.environ.get("GAR_FUSE_NORM_MAXB", "16"))     # RMSNorm folded into the skinny GEMM prologue (every block redoes x*g: only pays for <= 16 rows)
         for li, ly in enumerate(self.layers):
             if fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
