@@ -340,3 +340,56 @@ def test_replica_from_shapes_after_weight_copy(tiny):
         o0 = src.generate(**s, max_new_tokens=6, return_logits=True)
         o1 = dst.generate(**s, max_new_tokens=6, return_logits=True)
         assert torch.equal(o0.sequences, o1.sequences) and torch.equal(o0.logits, o1.logits)
+
+
+def test_f32_parity_gar1b_dims_max_tiles_one_layer():
+    """PLM's default max_num_tiles=36 (6x6 canvas -> 37 tiles, S ~ 9.8k) at GAR-1B shapes with one
+    layer each: the largest single-region configuration, f32 token parity with the oracle."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b(**{"vision.depth": 1, "text.num_hidden_layers": 1})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=36)
+    s = _sample(cfg, proc, 2, 1024, 1024)
+    assert s["pixel_values"].shape[0] == 37 and s["input_ids"].shape[1] > 9700
+    ref_seq, ref_logits = _oracle(W, cfg, s, 2, attn_impl="sdpa")
+    m = GARModel(cfg, W, torch.float32)
+    out = m.generate(**s, max_new_tokens=2, return_logits=True)
+    err = float((out.logits.cpu() - ref_logits).abs().max())
+    assert err <= F32_LOGIT_TOL * float(ref_logits.abs().max()), err
+    assert out.sequences.cpu().tolist() == ref_seq.tolist()
+
+
+def test_edge_cases_tiny(tiny):
+    """single new token (no decode loop), text-only prompt (no pixel_values: LlamaModel over token embeddings only),
+    and a batch of identical samples in bf16 whose rows must be identical."""
+    from gar_amd.modeling_gar import GARModel
+    from oracle import gar_oracle as O
+    cfg, W, proc = tiny
+    s = _sample(cfg, proc, 3)
+    m = GARModel(cfg, W, torch.float32)
+    ref_seq, _ = _oracle(W, cfg, s, 1)
+    assert m.generate(**s, max_new_tokens=1).sequences.cpu().tolist() == ref_seq.tolist()
+    ids = torch.tensor([[296, 306, 20, 21, 22, 307, 101, 102, 103, 309]], dtype=torch.int64)
+    tcfg = cfg.mllm_config.text_config
+    cache = O.KVCache(tcfg.num_hidden_layers)
+    emb = torch.nn.functional.embedding(ids, W[O.LM + "embed_tokens.weight"])
+    toks = []
+    h = O.llama_forward(emb, W, tcfg, cache, "eager")
+    head = O.lm_head_weight(W, tcfg)
+    for _ in range(5):
+        nxt = torch.argmax(torch.nn.functional.linear(h[:, -1], head), -1)
+        toks.append(int(nxt))
+        h = O.llama_forward(torch.nn.functional.embedding(nxt, W[O.LM + "embed_tokens.weight"]).unsqueeze(1), W, tcfg,
+                            cache, "eager")
+    out = m.generate(input_ids=ids, max_new_tokens=5)
+    assert out.sequences.cpu().tolist() == [toks]
+    mb = GARModel(cfg, W, torch.bfloat16)
+    sb = _sample(cfg, proc, 3, dtype=torch.bfloat16)
+    three = dict(input_ids=torch.cat([sb["input_ids"]] * 3), pixel_values=torch.cat([sb["pixel_values"]] * 3),
+                 global_mask_values=torch.cat([sb["global_mask_values"]] * 3), bboxes=sb["bboxes"] * 3,
+                 aspect_ratios=torch.cat([sb["aspect_ratios"]] * 3))
+    seq = mb.generate(**three, max_new_tokens=6).sequences
+    assert torch.equal(seq[0], seq[1]) and torch.equal(seq[0], seq[2])
