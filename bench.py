@@ -233,16 +233,18 @@ def main():
             except Exception:
                 pass
     value = world * args.steps * B / elapsed
-    line = {"metric": "regions/sec (1024^2 img, 1 mask, 64-tok caption) GAR-1B", "value": value, "unit": "regions/s",
+    mname = {"gar_1b": "GAR-1B", "gar_8b": "GAR-8B"}.get(args.model, args.model)
+    cfg_idx = {"gar_1b": "configs[1]", "gar_8b": "configs[3] shape, one GPU"}.get(args.model, "parity config")
+    line = {"metric": f"regions/sec (1024^2 img, 1 mask, 64-tok caption) {mname}", "value": value, "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "GAR-1B bf16, synthetic 1024x1024 images, 1 mask/region, 64-token greedy caption "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": f"{mname} bf16, synthetic 1024x1024 images, 1 mask/region, 64-token greedy caption "
+                                   f"(BASELINE.json {cfg_idx})",
                        "regions_per_step_per_gpu": B, "tiles_per_region": tiles, "prefill_len": S,
                        "new_tokens": args.new_tokens, "max_num_tiles": args.max_num_tiles,
                        "inputs": "resident in HBM" if args.preprocess == "resident" else
                                  "built per step from host images (device preprocessing inside the timed region)",
-                       "weights": "seeded synthetic GAR-1B", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
+                       "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},
             "roofline": roof}
     if "gemm_skinny_bf16" in agg:
