@@ -145,6 +145,30 @@ def test_norms(dev, dt, D):
     close(y, w.double() * n, dt)
 
 
+@pytest.mark.parametrize("D", [192, 1024])
+def test_norms_two_rows_per_wave_path(dev, D):
+    """bf16, D <= 1024, M >= 4096 takes the two-rows-per-wave kernel: odd M (last wave has one row), in-place, and it
+    must agree bit for bit with the one-row kernel (same arithmetic order per row)."""
+    from gar_amd import ops
+    dt = torch.bfloat16
+    M = 4097
+    x = q(rnd(M, D, seed=13, scale=2.0) + 0.3, dt)
+    w, b = q(1 + 0.1 * rnd(D, seed=14), dt), q(0.1 * rnd(D, seed=15), dt)
+    xd_, wd_, bd_ = x.to(dev, dt), w.to(dev, dt), b.to(dev, dt)
+    y = torch.empty(M, D, dtype=dt, device=dev)
+    ops.layernorm(xd_, wd_, bd_, 1e-5, out=y)
+    close(y, F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5), dt)
+    y1 = torch.empty(37, D, dtype=dt, device=dev)
+    ops.layernorm(xd_[-37:].contiguous(), wd_, bd_, 1e-5, out=y1)          # M = 37: one-row kernel
+    assert torch.equal(y[-37:], y1)
+    z = xd_.clone()
+    ops.layernorm(z, wd_, bd_, 1e-5)                                        # in place
+    assert torch.equal(z, y)
+    ops.rmsnorm(xd_, wd_, 1e-5, out=y)
+    ops.rmsnorm(xd_[-37:].contiguous(), wd_, 1e-5, out=y1)
+    assert torch.equal(y[-37:], y1)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DT)
 def test_patch_embed_with_mask_matches_two_convs(dev, dt):
