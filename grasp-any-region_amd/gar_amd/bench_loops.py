@@ -1,0 +1,174 @@
+"""Benchmark inference loops: counterparts of the reference's evaluation/GAR-Bench/inference.py
+and evaluation/DLC-Bench/inference.py on the MI355X path. Same flags, question templates, output JSON formats and the
+VQA exact-match accuracy print-out; masks are decoded with ``gar_amd.rle`` instead of pycocotools. Items are sharded
+round-robin over the ranks of a torchrun launch (one replica per GPU) and gathered on rank 0."""
+from __future__ import annotations
+
+import argparse
+import ast
+import json
+import os
+
+import torch
+from PIL import Image
+
+from . import dp, rle
+
+TORCH_DTYPE_MAP = dict(bf16=torch.bfloat16, fp32=torch.float32)
+
+
+def base_parser(description, default_model, default_cache, default_images):
+    ap = argparse.ArgumentParser(description=description)
+    ap.add_argument("--model_name_or_path", default=default_model,
+                    help="checkpoint directory; with --synthetic_weights a size name: gar_1b | gar_8b | tiny")
+    ap.add_argument("--cache_name", type=str, default=default_cache, help="cache name for saving results")
+    ap.add_argument("--anno_file", required=True, help="annotation file path")
+    ap.add_argument("--image_folder", default=default_images, help="the folder of images")
+    ap.add_argument("--data_type", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device", default=None, help="default: cuda:LOCAL_RANK")
+    ap.add_argument("--max_num_tiles", type=int, default=16)
+    ap.add_argument("--max_new_tokens", type=int, default=1024)
+    ap.add_argument("--output_dir", default=None, help="default: the reference's model_outputs directory")
+    ap.add_argument("--limit", type=int, default=0, help="only the first N items (smoke runs)")
+    ap.add_argument("--host_preprocessing", action="store_true")
+    ap.add_argument("--synthetic_weights", action="store_true")
+    return ap
+
+
+def load(args):
+    from .configuration_gar import GARConfig
+    from .modeling_gar import GARModel
+    from .processing import GARProcessor
+    rank, local, world = dp.init_distributed()
+    device = args.device or f"cuda:{local}"
+    torch.cuda.set_device(torch.device(device))
+    dtype = TORCH_DTYPE_MAP[args.data_type]
+    torch.manual_seed(args.seed)
+    if args.synthetic_weights:
+        name = args.model_name_or_path if args.model_name_or_path in ("gar_1b", "gar_8b", "tiny") else "gar_1b"
+        cfg = getattr(GARConfig, name)()
+        model = GARModel.from_synthetic(cfg, args.seed, dtype, device)
+        processor = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles)
+    else:
+        model = GARModel.from_pretrained(args.model_name_or_path, dtype, device)
+        processor = GARProcessor.from_pretrained(args.model_name_or_path, model.config, args.max_num_tiles)
+    if not args.host_preprocessing:
+        processor.use_gpu_preprocessing(device, dtype)
+    return model.eval(), processor, dtype, device, rank, world
+
+
+def _generate(model, processor, sample, args, skip_special_tokens):
+    out = model.generate(**sample, generation_config=dict(
+        max_new_tokens=args.max_new_tokens, do_sample=False, eos_token_id=processor.tokenizer.eos_token_id,
+        pad_token_id=processor.tokenizer.pad_token_id), return_dict=True)
+    return processor.tokenizer.decode(out.sequences[0], skip_special_tokens=skip_special_tokens).strip()
+
+
+def _gather(local, rank, world):
+    """[(index, value)] from every rank -> index-sorted list on rank 0 (None elsewhere)."""
+    if world == 1:
+        return [v for _, v in sorted(local, key=lambda t: t[0])]
+    import torch.distributed as dist
+    allr = [None] * world
+    dist.all_gather_object(allr, local)
+    if rank != 0:
+        return None
+    return [v for _, v in sorted((t for part in allr for t in part), key=lambda t: t[0])]
+
+
+def gar_bench_question(item, mode):
+    """evaluation/GAR-Bench/inference.py:124-135"""
+    if mode == "vqa":
+        q = f"Question: {item['question']}\nOptions:"
+        for op in item["choices"]:
+            q += f"\n{op}"
+        return q + "\nAnswer with the correct option's letter directly."
+    if mode == "simple":
+        return item["question"]
+    if mode == "detailed":
+        return "Describe <Prompt0> in detail, including the relationship with <Prompt1>."
+    raise NotImplementedError(mode)
+
+
+def run_gar_bench(argv=None):
+    from .eval_dataset import MultiRegionDataset
+    ap = base_parser("Inference of Grasp Any Region models on GAR-Bench (MI355X-native path).", "HaochenWang/GAR-8B",
+                     "gar_8b", "evaluation/GAR-Bench/annotations")
+    ap.add_argument("--mode", choices=["vqa", "simple", "detailed"], required=True, help="mode to build questions")
+    args = ap.parse_args(argv)
+    model, processor, dtype, device, rank, world = load(args)
+    data = json.load(open(args.anno_file))
+    if args.limit:
+        data = data[:args.limit]
+    prompt_number = model.config.prompt_numbers
+    prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
+    local = []
+    for idx in dp.shard_indices(len(data), rank, world):
+        item = data[idx]
+        img = Image.open(os.path.join(args.image_folder, item["image"]))
+        masks = [(rle.decode(r) * 255).astype("uint8") for r in item["mask_rles"]]
+        ds = MultiRegionDataset(image=img, masks=masks, question_str=gar_bench_question(item, args.mode),
+                                processor=processor, prompt_number=prompt_number, visual_prompt_tokens=prompt_tokens,
+                                data_dtype=dtype, device=device)
+        text = _generate(model, processor, ds[0], args, skip_special_tokens=False)
+        if text.endswith("<|eot_id|>"):
+            text = text.replace("<|eot_id|>", "")
+        print(text, flush=True)
+        local.append((idx, dict(item, model_output=text)))
+    outputs = _gather(local, rank, world)
+    if outputs is None:
+        return None
+    cache = f"{args.cache_name}_{args.mode}"
+    print(f"Cache name: {cache}")
+    out_dir = args.output_dir or "evaluation/GAR-Bench/model_outputs"
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{cache}.json")
+    json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    if args.mode == "vqa":      # exact-match accuracy per category and overall (:185-203)
+        for cat in sorted(set(x["type"] for x in outputs)):
+            res = [x for x in outputs if x["type"] == cat]
+            ok = len([x for x in res if x["model_output"].lower() == x["answer"].lower()])
+            print(f"{cat}: [{ok}/{len(res)}]={round(ok / len(res) * 100, 1)}")
+        ok = len([x for x in outputs if x["model_output"].lower() == x["answer"].lower()])
+        print(f"=> overall: [{ok}/{len(outputs)}]={round(ok / len(outputs) * 100, 1)}")
+    return path
+
+
+def run_dlc_bench(argv=None):
+    """COCO-style annotation file (an Objects365 subset): one caption per annotation, keyed by annotation id
+    (evaluation/DLC-Bench/inference.py:108-166)."""
+    from .eval_dataset import SingleRegionCaptionDataset
+    ap = base_parser("Inference of Grasp Any Region models on DLC-Bench (MI355X-native path).", "HaochenWang/GAR-8B",
+                     "gar_8b", "evaluation/DLC-Bench/annotations")
+    args = ap.parse_args(argv)
+    model, processor, dtype, device, rank, world = load(args)
+    coco = json.load(open(args.anno_file))
+    imgs = {str(i["id"]): i for i in coco["images"]}
+    anns = coco["annotations"]          # the reference walks images, then each image's annotations: same set
+    order = sorted(range(len(anns)), key=lambda k: (list(imgs).index(str(anns[k]["image_id"])), k))
+    if args.limit:
+        order = order[:args.limit]
+    prompt_number = model.config.prompt_numbers
+    prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
+    local = []
+    for j in dp.shard_indices(len(order), rank, world):
+        a = anns[order[j]]
+        seg = ast.literal_eval(a["segmentation"]) if isinstance(a["segmentation"], str) else a["segmentation"]
+        mask = rle.decode(seg)
+        info = imgs[str(a["image_id"])]
+        img = Image.open(os.path.join(args.image_folder, "images", info["file_name"]))
+        ds = SingleRegionCaptionDataset(image=img, mask=mask, processor=processor, prompt_number=prompt_number,
+                                        visual_prompt_tokens=prompt_tokens, data_dtype=dtype, device=device)
+        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
+        print(text, flush=True)
+        local.append((j, (a["id"], text)))
+    outputs = _gather(local, rank, world)
+    if outputs is None:
+        return None
+    out_dir = args.output_dir or "evaluation/DLC-Bench/model_outputs"
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{args.cache_name}.json")
+    json.dump({k: v for k, v in outputs}, open(path, "w"), indent=4, ensure_ascii=False)
+    print(f"Cache name: {args.cache_name}")
+    return path

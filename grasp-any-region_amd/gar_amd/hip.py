@@ -50,6 +50,7 @@ SIGNATURES = {
     "gar_resize_bicubic_h": ([_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
     "gar_resize_bicubic_v_tiles": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _vp], _i),
     "gar_resize_nearest_tiles": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp], _i),
+    "gar_rle_decode": ([C.c_char_p, _i64, _i, _i, _vp], _i64),
     "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),

@@ -184,6 +184,11 @@ int gar_resize_nearest_tiles(int dtype, const uint8_t* src, void* out, int H, in
                              int ncw, int tile0, const int32_t* xi, const int32_t* yi, float mean, float stdv,
                              gar_stream_t stream);
 
+/* COCO compressed run-length mask -> row-major [h, w] bytes (host memory, CPU): what `pycocotools.mask.decode`
+ * does for the `mask_rles` / `segmentation` entries the benchmark loops read (evaluation/GAR-Bench/inference.py:142-145,
+ * evaluation/DLC-Bench/inference.py:121-122). Returns the foreground pixel count, or a negative error code. */
+int64_t gar_rle_decode(const char* counts, int64_t len, int h, int w, uint8_t* mask);
+
 /* Decode-step helpers (HF GenerationMixin greedy loop, modeling_gar.py:418-426):
  * embedding gather for the just-sampled tokens; argmax over logits with first-index tie break writing
  * out_tokens[b*out_stride + step_dev[0]] and cur_tokens[b]; device-side counters (position / step) so one captured

@@ -1,0 +1,76 @@
+"""GPU (-m gpu): the benchmark inference loops end to end on synthetic annotation files with
+seeded tiny weights: output JSON formats of the reference scripts, VQA accuracy print-out, RLE masks through
+gar_rle_decode, and agreement of every generated answer with a direct `generate` on the same sample."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluation", script, "inference.py"), "--synthetic_weights",
+                        "--model_name_or_path", "tiny", "--data_type", "fp32", "--max_num_tiles", "4",
+                        "--max_new_tokens", "8", *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def test_gar_bench_and_dlc_bench_loops(tmp_path):
+    from gar_amd import GARConfig, rle
+    from gar_amd.eval_dataset import MultiRegionDataset
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.synthetic import synthetic_disjoint_masks, synthetic_image, synthetic_mask
+    os.makedirs(tmp_path / "images")
+    items = []
+    for i in range(3):
+        synthetic_image(20 + i, 260, 200).save(tmp_path / "images" / f"vqa_{i}.png")
+        nm = 2 + (i % 2)
+        masks = synthetic_disjoint_masks(20 + i, nm, 260, 200)
+        names = " or ".join(f"<Prompt{k}>" for k in range(nm))
+        items.append({"image": f"images/vqa_{i}.png", "mask_rles": [rle.encode(m) for m in masks],
+                      "question": f"Which one is larger, {names}?",
+                      "choices": [f"{'ABC'[k]}. <Prompt{k}>" for k in range(nm)],
+                      "answer": "A", "type": "size" if i < 2 else "shape"})
+    anno = tmp_path / "vqa.json"
+    json.dump(items, open(anno, "w"))
+    out = _run("GAR-Bench", "--anno_file", str(anno), "--image_folder", str(tmp_path), "--mode", "vqa", "--cache_name", "t",
+               "--output_dir", str(tmp_path / "out"))
+    res = json.load(open(tmp_path / "out" / "t_vqa.json"))
+    assert len(res) == 3 and all("model_output" in r and r["image"] == items[k]["image"] for k, r in enumerate(res))
+    assert "=> overall: [" in out and "size: [" in out and "shape: [" in out and "Cache name: t_vqa" in out
+    # the loop's answer == a direct generate on the sample the loop builds
+    from gar_amd.bench_loops import gar_bench_question
+    cfg = GARConfig.tiny()
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4)
+    model = GARModel.from_synthetic(cfg, 0, torch.float32)
+    from PIL import Image
+    it = items[1]
+    masks = [(rle.decode(r) * 255).astype(np.uint8) for r in it["mask_rles"]]
+    pt = [f"<Prompt{i}>" for i in range(cfg.prompt_numbers)] + ["<NO_Prompt>"]
+    s = MultiRegionDataset(image=Image.open(tmp_path / it["image"]), masks=masks, question_str=gar_bench_question(it, "vqa"),
+                           processor=proc, prompt_number=cfg.prompt_numbers, visual_prompt_tokens=pt,
+                           data_dtype=torch.float32, device="cuda:0")[0]
+    o = model.generate(**s, generation_config=dict(max_new_tokens=8, do_sample=False, eos_token_id=proc.tokenizer.eos_token_id,
+                                                   pad_token_id=proc.tokenizer.pad_token_id))
+    txt = proc.tokenizer.decode(o.sequences[0], skip_special_tokens=False).strip().replace("<|eot_id|>", "")
+    assert res[1]["model_output"] == txt
+    # DLC-Bench: COCO-style file, stringified fields as in the reference's annotations.json
+    coco = {"images": [{"id": 7, "file_name": "vqa_0.png", "height": 200, "width": 260},
+                       {"id": 9, "file_name": "vqa_1.png", "height": 200, "width": 260}],
+            "annotations": [{"id": "101", "image_id": "9", "segmentation": str(rle.encode(synthetic_mask(31, 260, 200)))},
+                            {"id": "102", "image_id": "7", "segmentation": rle.encode(synthetic_mask(32, 260, 200))},
+                            {"id": "103", "image_id": "7", "segmentation": rle.encode(synthetic_mask(33, 260, 200))}]}
+    ca = tmp_path / "coco.json"
+    json.dump(coco, open(ca, "w"))
+    out = _run("DLC-Bench", "--anno_file", str(ca), "--image_folder", str(tmp_path), "--cache_name", "d",
+               "--output_dir", str(tmp_path / "out"))
+    res = json.load(open(tmp_path / "out" / "d.json"))
+    assert list(res.keys()) == ["102", "103", "101"] and all(isinstance(v, str) for v in res.values())   # image order

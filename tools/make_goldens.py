@@ -230,8 +230,30 @@ def golden_torch_ops():
                         ln_y=z.numpy(), gelu_y=g.numpy(), q=q.numpy(), k=k.numpy(), v=v.numpy(), sdpa=a.numpy())
 
 
+def golden_rle_samples():
+    """COCO run-length masks the reference's benchmark annotation files hold (data): a few `segmentation` entries of
+    evaluation/DLC-Bench/annotations/annotations.json together with that file's own `bbox` / image size for the same
+    object, and a few `mask_rles` of evaluation/GAR-Bench/annotations/GAR-Bench-VQA.json."""
+    import ast
+    import json
+    ref = os.environ.get("GAR_REFERENCE", "/root/reference")
+    d = json.load(open(os.path.join(ref, "evaluation/DLC-Bench/annotations/annotations.json")))
+    imgs = {str(i["id"]): i for i in d["images"]}
+    out = {"dlc": [], "gar_bench": []}
+    for a in d["annotations"][:6]:
+        seg = ast.literal_eval(a["segmentation"]) if isinstance(a["segmentation"], str) else a["segmentation"]
+        bb = ast.literal_eval(a["bbox"]) if isinstance(a["bbox"], str) else a["bbox"]
+        im = imgs[str(a["image_id"])]
+        out["dlc"].append({"segmentation": seg, "bbox": bb, "image_hw": [im["height"], im["width"]]})
+    g = json.load(open(os.path.join(ref, "evaluation/GAR-Bench/annotations/GAR-Bench-VQA.json")))
+    for it in g[:3]:
+        out["gar_bench"].append({"mask_rles": it["mask_rles"]})
+    json.dump(out, open(os.path.join(OUT, "rle_samples.json"), "w"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    golden_rle_samples()
     golden_llama()
     golden_projector()
     golden_torch_ops()
