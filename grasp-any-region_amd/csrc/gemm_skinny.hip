@@ -20,7 +20,7 @@
 // side). Per-lane fragment loads from global memory touch 16 lines (half used) per instruction; for M = 64 the four
 // activation tiles re-read from L2 that way cost more than the weight stream itself (tools/bench_skinny.py).
 template <int EPI, int NT, int MT, bool NORM, bool STAGED>
-__global__ __launch_bounds__(NT >= 4 ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
+__global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,7 +275,8 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
         return merge > stg ? merge : stg;
     };
     int nw = 4;
-    const int max_nw = NT >= 4 ? 8 : 16;                 // 4-tile blocks are built for <= 512 threads (256 VGPRs)
+    // 4-tile blocks and the fused-norm 4-row-tile blocks are built for <= 512 threads (256 VGPRs)
+    const int max_nw = (NT >= 4 || (p.norm_w && MT >= 4)) ? 8 : 16;
     while (nw < max_nw && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && lds_for(nw * 2) <= MAXLDS) nw *= 2;
     const int lds = lds_for(nw);
 #define LAUNCH_SK(NORM_, ST_) \
