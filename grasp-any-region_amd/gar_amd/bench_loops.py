@@ -172,3 +172,84 @@ def run_dlc_bench(argv=None):
     json.dump({k: v for k, v in outputs}, open(path, "w"), indent=4, ensure_ascii=False)
     print(f"Cache name: {args.cache_name}")
     return path
+
+
+def _single_region_loop(args, items, get_image, get_mask, make_record):
+    """Shared body of the Ferret-Bench / MDVP-Bench loops: one SingleRegionCaptionDataset sample per item."""
+    from .eval_dataset import SingleRegionCaptionDataset
+    model, processor, dtype, device, rank, world = load(args)
+    if args.limit:
+        items = items[:args.limit]
+    prompt_number = model.config.prompt_numbers
+    prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
+    local = []
+    for idx in dp.shard_indices(len(items), rank, world):
+        item = items[idx]
+        image_path, img = get_image(item)
+        mask = get_mask(item, img)
+        ds = SingleRegionCaptionDataset(image=img, mask=mask, processor=processor, prompt_number=prompt_number,
+                                        visual_prompt_tokens=prompt_tokens, data_dtype=dtype, device=device)
+        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
+        print(text, flush=True)
+        local.append((idx, make_record(item, image_path, text)))
+    return _gather(local, rank, world)
+
+
+def run_ferret_bench(argv=None):
+    """evaluation/Ferret-Bench/inference.py:67-163 — polygon (frPyObjects + merge) or RLE segmentations, records
+    {image_path, annotation, caption}."""
+    ap = base_parser("Inference of Grasp Any Region models on Ferret-Bench (MI355X-native path).", "HaochenWang/GAR-8B",
+                     "gar_8b", "evaluation/Ferret-Bench/annotations")
+    args = ap.parse_args(argv)
+    data = json.load(open(args.anno_file))
+
+    def get_image(item):
+        p = os.path.join(args.image_folder, item["image"])
+        return p, Image.open(p).convert("RGB")
+
+    def get_mask(item, img):
+        seg = item["annotation"]["segmentation"]
+        seg = ast.literal_eval(seg) if isinstance(seg, str) else seg
+        w, h = img.size
+        m = rle.from_polygons(seg, h, w) if isinstance(seg, list) else rle.decode(seg)
+        return (m * 255).astype("uint8")
+
+    outputs = _single_region_loop(args, data, get_image, get_mask,
+                                  lambda item, p, text: {"image_path": p, "annotation": item["annotation"], "caption": text})
+    if outputs is None:
+        return None
+    out_dir = args.output_dir or "evaluation/Ferret-Bench/model_outputs"
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{args.cache_name}.json")
+    json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    print(f"Cache name: {args.cache_name}")
+    return path
+
+
+def run_mdvp_bench(argv=None):
+    """evaluation/MDVP-Bench/inference.py:108-161 — `mask_rle` entries, default max_num_tiles 8, records
+    {image_path, caption, gt}."""
+    ap = base_parser("Inference of Grasp Any Region models on MDVP-Bench (MI355X-native path).", "HaochenWang/GAR-1B",
+                     "gar_1b", "evaluation/MDVP-Bench/data")
+    ap.set_defaults(max_num_tiles=8, anno_file="evaluation/MDVP-Bench/annotations/mdvp_caption_mask.json")
+    for a in ap._actions:
+        if a.dest == "anno_file":
+            a.required = False
+    args = ap.parse_args(argv)
+    data = json.load(open(args.anno_file))
+
+    def get_image(item):
+        p = os.path.join(args.image_folder, item["image_path"])
+        return p, Image.open(p).convert("RGB")
+
+    outputs = _single_region_loop(args, data, get_image,
+                                  lambda item, img: (rle.decode(item["mask_rle"]) * 255).astype("uint8"),
+                                  lambda item, p, text: {"image_path": p, "caption": text, "gt": item["caption"]})
+    if outputs is None:
+        return None
+    out_dir = args.output_dir or "evaluation/MDVP-Bench/model_outputs"
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{args.cache_name}.json")
+    json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    print(f"Cache name: {args.cache_name}")
+    return path

@@ -74,3 +74,33 @@ def test_gar_bench_and_dlc_bench_loops(tmp_path):
                "--output_dir", str(tmp_path / "out"))
     res = json.load(open(tmp_path / "out" / "d.json"))
     assert list(res.keys()) == ["102", "103", "101"] and all(isinstance(v, str) for v in res.values())   # image order
+
+
+def test_ferret_and_mdvp_loops(tmp_path):
+    """polygon segmentations (Ferret-Bench; stringified fields like the reference's file) and `mask_rle` entries
+    (MDVP-Bench): record formats of the reference scripts."""
+    from gar_amd import rle
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    os.makedirs(tmp_path / "img")
+    for i in range(2):
+        synthetic_image(40 + i, 240, 180).save(tmp_path / "img" / f"f{i}.jpg")
+    ferret = [{"question_id": 0, "image": "img/f0.jpg", "category": "refer_desc", "text": "q",
+               "annotation": {"bbox": "[30.5, 20.25, 100.0, 80.0]",
+                              "segmentation": "[[30.5, 20.25, 130.5, 20.25, 130.5, 100.25, 30.5, 100.25]]"}},
+              {"question_id": 1, "image": "img/f1.jpg", "category": "refer_desc", "text": "q",
+               "annotation": {"bbox": [10, 10, 50, 60], "segmentation": rle.encode(synthetic_mask(41, 240, 180))}}]
+    fa = tmp_path / "ferret.json"
+    json.dump(ferret, open(fa, "w"))
+    _run("Ferret-Bench", "--anno_file", str(fa), "--image_folder", str(tmp_path), "--cache_name", "f",
+         "--output_dir", str(tmp_path / "out"))
+    res = json.load(open(tmp_path / "out" / "f.json"))
+    assert [sorted(r) for r in res] == [["annotation", "caption", "image_path"]] * 2
+    assert res[0]["annotation"] == ferret[0]["annotation"] and res[1]["image_path"].endswith("img/f1.jpg")
+    mdvp = [{"image_path": f"img/f{i}.jpg", "mask_rle": rle.encode(synthetic_mask(50 + i, 240, 180)),
+             "dataset_name": "x", "question": "q", "caption": f"gt{i}"} for i in range(2)]
+    ma = tmp_path / "mdvp.json"
+    json.dump(mdvp, open(ma, "w"))
+    _run("MDVP-Bench", "--anno_file", str(ma), "--image_folder", str(tmp_path), "--cache_name", "m",
+         "--output_dir", str(tmp_path / "out"))
+    res = json.load(open(tmp_path / "out" / "m.json"))
+    assert [r["gt"] for r in res] == ["gt0", "gt1"] and all(isinstance(r["caption"], str) for r in res)

@@ -226,3 +226,23 @@ def test_coco_rle_against_reference_annotation_samples(golden_dir):
     from gar_amd import hip
     with pytest.raises(hip.GarError):
         rle.decode({"size": [4, 4], "counts": "3"})          # covers 3 of 16 pixels
+
+
+def test_polygon_rasteriser_known_answers():
+    """rle.from_polygons (COCO frPyObjects + merge + decode, restated — parity unpinned, pycocotools is not available):
+    axis-aligned rectangles of the kind the reference's Ferret-Bench annotations hold cover exactly their pixel box,
+    a right triangle has its analytic area, the union of overlapping polygons is a union, and clipping at the image
+    border works."""
+    import numpy as np
+    from gar_amd import rle
+    m = rle.from_polygons([[230.39, 52.48, 286.41, 52.48, 286.41, 84.48, 230.39, 84.48]], 480, 640)   # annotation 0
+    ys, xs = np.nonzero(m)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (230, 285, 52, 83) and m.sum() == 56 * 32
+    t = rle.from_polygons([[10.0, 10.0, 110.0, 10.0, 10.0, 60.0]], 100, 150)
+    assert t.sum() == 2500 and t[10, 10] == 1 and t[59, 10] == 1 and t[59, 30] == 0
+    a = [10.0, 10.0, 50.0, 10.0, 50.0, 50.0, 10.0, 50.0]
+    b = [30.0, 30.0, 70.0, 30.0, 70.0, 70.0, 30.0, 70.0]
+    u = rle.from_polygons([a, b], 100, 100)
+    assert u.sum() == 1600 + 1600 - 400
+    c = rle.from_polygons([[-20.0, -20.0, 30.0, -20.0, 30.0, 30.0, -20.0, 30.0]], 64, 64)
+    assert c.sum() == 30 * 30 and c[0, 0] == 1
