@@ -46,6 +46,14 @@ def _worker(rank, world, port, out_dir):
         assert got is None
     dp.barrier()
     assert dp.max_over_ranks(float(rank + 1), device="cpu") == float(world)
+    # ---- benchmark loops: per-rank (index, record) lists -> index-ordered list on rank 0
+    from gar_amd.bench_loops import _gather
+    items = [(i, {"id": i, "text": f"caption {i}"}) for i in dp.shard_indices(5, rank, world)]
+    merged = _gather(items, rank, world)
+    if rank == 0:
+        assert [m["id"] for m in merged] == [0, 1, 2, 3, 4]
+    else:
+        assert merged is None
     with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
         f.write("ok")
     torch.distributed.destroy_process_group()
