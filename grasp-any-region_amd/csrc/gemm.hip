@@ -342,6 +342,11 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
                           (e == GAR_EPI_NONE || e == GAR_EPI_RES || e == GAR_EPI_SWIGLU ||
                            (e == GAR_EPI_BIAS && dtype == GAR_BF16) || dtype == GAR_F32),
                       "gar_gemm: fused RMSNorm prologue is built for the decode path only (M <= 64 bf16 / 16 f32)");
+    if (e == GAR_EPI_QKV_ROPE)
+        GAR_CHECK_ARG(p.bias && p.qkv_q && p.qkv_k && p.qkv_sin && p.qkv_cos && p.qkv_heads > 0 && p.qkv_head_dim % 8 == 0 &&
+                          p.N == 3 * p.qkv_heads * p.qkv_head_dim && p.qkv_tokens > 0 && p.M % p.qkv_tokens == 0 &&
+                          p.qkv_tokens_pad >= p.qkv_tokens && p.qkv_prefix >= 0 && p.qkv_prefix <= p.qkv_tokens,
+                      "gar_gemm: QKV_ROPE args");
     if (e == GAR_EPI_PATCH_POS)
         GAR_CHECK_ARG(p.pos && p.tokens_in > 0 && p.tokens_out >= p.tokens_in + p.token_offset && p.N % 4 == 0,
                       "gar_gemm: PATCH_POS args");
@@ -355,6 +360,15 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
         case GAR_EPI_RES: rc = launch<GAR_EPI_RES>(dtype, p, s); break;
         case GAR_EPI_SWIGLU: rc = launch<GAR_EPI_SWIGLU>(dtype, p, s); break;
         case GAR_EPI_PATCH_POS: rc = launch<GAR_EPI_PATCH_POS>(dtype, p, s); break;
+        case GAR_EPI_QKV_ROPE:
+            // fused front half of timm AttentionRope: bf16, shapes the ping-pong kernel takes; otherwise the caller
+            // keeps GAR_EPI_BIAS + gar_vit_qkv_post
+            if (dtype != GAR_BF16 || !gar_gemm_pp_try(p, s)) {
+                gar_set_error("gar_gemm: QKV_ROPE epilogue is built for the bf16 ping-pong kernel only (M=%d N=%d)", p.M, p.N);
+                return GAR_ERR_UNSUPPORTED;
+            }
+            rc = GAR_OK;
+            break;
         default: gar_set_error("gar_gemm: unknown epilogue %d", e); return GAR_ERR_ARG;
     }
     if (rc != GAR_OK) return rc;

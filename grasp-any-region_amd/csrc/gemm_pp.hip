@@ -185,13 +185,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     // 8-column groups: every global access of a wave instruction is 2 rows x 512 contiguous bytes.
     // Called with both wave rows aligned; 2 barriers per 64-row chunk.
     auto epilogue_lds = [&](char* E) {
-        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES;
+        constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;
+        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES || QKV;
         constexpr bool HAS_RES = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES;
         // a thread always serves the same 8-column group (cg = tid & 31): bias / LayerScale are loaded once per tile
         const int cg = tid & 31, r0 = tid >> 5;
         const int n = n0 + cg * 8;
         const bool nok = n < p.N;
         float bias8[8], gam8[8];
+        // QKV_ROPE: this thread's 8 columns are dims d..d+7 of head h of q (part 0), k (1) or v (2)
+        const int Da = p.qkv_heads * p.qkv_head_dim;
+        const int part = QKV ? n / Da : 0;
+        const int nn = QKV ? n - part * Da : 0;
+        const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
         if (HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
 #pragma unroll
@@ -260,7 +266,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             }
                         }
                     }
-                    st8((bf16_t*)p.C + off[k], o);
+                    if (QKV) {
+                        const int m = m0 + c * 64 + k * 16 + r0;
+                        const int tile = m / p.qkv_tokens, tok = m - tile * p.qkv_tokens;
+                        if (part < 2) {
+                            if (tok >= p.qkv_prefix) {      // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs
+                                float s8[8], c8[8];
+                                const int64_t ro = (int64_t)(tok - p.qkv_prefix) * p.qkv_head_dim + qd;
+                                ld8(p.qkv_sin + ro, s8);
+                                ld8(p.qkv_cos + ro, c8);
+#pragma unroll
+                                for (int e = 0; e < 8; e += 2) {
+                                    const float x0 = o[e], x1 = o[e + 1];
+                                    o[e] = x0 * c8[e] + (-x1) * s8[e];
+                                    o[e + 1] = x1 * c8[e + 1] + x0 * s8[e + 1];
+                                }
+                            }
+                            if (part == 0) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] *= p.qkv_q_scale;
+                            }
+                            bf16_t* dst = (bf16_t*)(part == 0 ? p.qkv_q : p.qkv_k) +
+                                          (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd;
+                            st8(dst, o);
+                        } else {
+                            st8((bf16_t*)p.C + (int64_t)m * p.ldc + nn, o);
+                        }
+                    } else {
+                        st8((bf16_t*)p.C + off[k], o);
+                    }
                 }
             }
             __builtin_amdgcn_s_barrier();
@@ -347,7 +381,8 @@ static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hip
     static const int perm = [] { const char* e = getenv("GAR_GEMM_PERM"); return e ? atoi(e) : 1; }();
     static const int persist = [] { const char* e = getenv("GAR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
     const int grid = persist ? min(pm * pn, num_cus) : pm * pn;
-    if (perm) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
+    if (perm || EPI == GAR_EPI_QKV_ROPE)      // the fused qkv epilogue exists in the row-coalesced (PERM) form only
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
     else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, false>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
 }
 
@@ -379,6 +414,7 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
         case GAR_EPI_RES: launch_pp<GAR_EPI_RES>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_SWIGLU: launch_pp<GAR_EPI_SWIGLU>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_PATCH_POS: launch_pp<GAR_EPI_PATCH_POS>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_QKV_ROPE: launch_pp<GAR_EPI_QKV_ROPE>(p, pm, pn, num_cus, s); break;
         default: return false;
     }
     return true;

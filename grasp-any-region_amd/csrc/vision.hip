@@ -178,6 +178,55 @@ extern "C" int gar_vit_qkv_post(int dtype, const void* qkv, const float* sn, con
     return GAR_OK;
 }
 
+// vit_v_transpose: the V third of vit_qkv_post for the fused qkv GEMM (GAR_EPI_QKV_ROPE writes q / k in place):
+// V [T*N, H*HD] row-major -> Vt [T, H, HD, Npad] (zero for tokens >= N), through LDS so rows of Vt are full lines.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void vit_v_transpose_kernel(const T* __restrict__ V, T* __restrict__ Vt, int N, int H,
+                                                              int Npad) {
+    constexpr int LPT = HD / 8, TPP = 256 / LPT;
+    __shared__ T vs[64 * (HD + 2)];
+    const int chunks = Npad / 64;
+    const int ch = blockIdx.x % chunks;
+    const int h = (blockIdx.x / chunks) % H;
+    const int t = blockIdx.x / (chunks * H);
+    const int D = H * HD, tid = threadIdx.x, d8 = (tid % LPT) * 8;
+    for (int pass = 0; pass < 64 / TPP; ++pass) {
+        const int nl = pass * TPP + tid / LPT, n = ch * 64 + nl;
+        float v[8];
+        if (n < N) ld8(V + ((int64_t)t * N + n) * D + h * HD + d8, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) DT<T>::st(&vs[nl * (HD + 2) + d8 + e], v[e]);
+    }
+    __syncthreads();
+    for (int d = tid / 8; d < HD; d += 32) {
+        const int n8 = (tid % 8) * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = DT<T>::ld(&vs[(n8 + e) * (HD + 2) + d]);
+        st8(Vt + (((int64_t)t * H + h) * HD + d) * Npad + ch * 64 + n8, o);
+    }
+}
+
+extern "C" int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T_, int N, int H, int hd, int Npad,
+                                   gar_stream_t stream) {
+    GAR_CHECK_ARG(V && Vt, "vit_v_transpose: null pointer");
+    GAR_CHECK_ARG(Npad % 64 == 0 && Npad >= N && N > 0 && T_ > 0 && H > 0, "vit_v_transpose: bad shape");
+    GAR_CHECK_ARG(hd == 64 || hd == 128, "vit_v_transpose: head_dim %d not built (64, 128)", hd);
+    dim3 grid(T_ * H * (Npad / 64)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_VT(TT, HD_) \
+    hipLaunchKernelGGL((vit_v_transpose_kernel<TT, HD_>), grid, block, 0, s, (const TT*)V, (TT*)Vt, N, H, Npad)
+    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_VT(bf16_t, 64); else LAUNCH_VT(bf16_t, 128); }
+    else { if (hd == 64) LAUNCH_VT(float, 64); else LAUNCH_VT(float, 128); }
+#undef LAUNCH_VT
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pool2x2: one thread per (out token, 8 channels); reads 4 x 16 B, writes 16 B.
 // algorithmic bytes = T*g*g*C*sizeof(T) read + a quarter of that written.

@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgar_hip.so")
 
 GAR_F32, GAR_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS = range(7)
-ABI_VERSION = 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
+ERR_UNSUPPORTED = -4
+ABI_VERSION = 2
 
 
 class GarError(RuntimeError):
@@ -24,7 +25,10 @@ class GemmParams(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("gamma", C.c_void_p), ("pos", C.c_void_p), ("tokens_in", C.c_int32), ("tokens_out", C.c_int32),
-                ("token_offset", C.c_int32), ("norm_eps", C.c_float), ("norm_w", C.c_void_p)]
+                ("token_offset", C.c_int32), ("norm_eps", C.c_float), ("norm_w", C.c_void_p),
+                ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_sin", C.c_void_p), ("qkv_cos", C.c_void_p),
+                ("qkv_heads", C.c_int32), ("qkv_head_dim", C.c_int32), ("qkv_tokens", C.c_int32),
+                ("qkv_tokens_pad", C.c_int32), ("qkv_prefix", C.c_int32), ("qkv_q_scale", C.c_float)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -38,6 +42,7 @@ SIGNATURES = {
     "gar_layernorm": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
     "gar_rmsnorm": ([_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "gar_vit_v_transpose": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp], _i),
     "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),

@@ -239,10 +239,15 @@ class GARModel:
         x = self._buf(key, "x", (Tt, N, D))
         hbuf = self._buf(key, "h", (Tt * N, D))
         qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
-        Q = self._buf(key, "Q", (Tt, H, Npad, hd))
-        K = self._buf(key, "K", (Tt, H, Npad, hd))
+        # zero-initialised once: the fused qkv GEMM writes the N real token rows only, rows N..Npad must stay finite
+        Q = self._buf(key, "Q", (Tt, H, Npad, hd), zero=True)
+        K = self._buf(key, "K", (Tt, H, Npad, hd), zero=True)
         Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
         att = self._buf(key, "att", (Tt * N, Da))
+        # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
+        # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
+        fused = self.dtype == torch.bfloat16 and os.environ.get("GAR_FUSED_QKV", "1") != "0"
+        vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
         x2 = x.view(Tt * N, D)
@@ -253,8 +258,14 @@ class GARModel:
         q_scale = (v.head_dim ** -0.5) * LOG2E
         for blk in self.vblocks:
             ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
-            ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
-            ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
+            if fused:
+                fused = ops.gemm_qkv_rope(hbuf, blk["qkv_w"], blk["qkv_b"], vrow, Q, K, self.vit_sin, self.vit_cos, H, hd, N,
+                                          Npad, self.npt, q_scale)
+            if fused:
+                ops.vit_v_transpose(vrow, Vt, Tt, N, H, hd, Npad)
+            else:
+                ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
+                ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
             ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
             ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])
             ops.layernorm(x2, *blk["n2"], v.ln_eps, out=hbuf)

@@ -119,6 +119,42 @@ def vit_qkv_post(qkv, sin, cos, Q, K, Vt, T, N, npt, H, hd, Npad, q_scale):
                                  H, hd, Npad, q_scale, stream()), "gar_vit_qkv_post")
 
 
+def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale) -> bool:
+    """qkv GEMM with the front half of timm AttentionRope fused (GAR_EPI_QKV_ROPE): q / k are rotated, scaled and written
+    straight into Q / K [tiles, heads, tokens_pad, hd]; v goes row-major to ``v_out`` [M, heads*hd]. Returns False when the
+    library does not take this shape / dtype on the fused path (caller keeps gemm + vit_qkv_post)."""
+    M, Kd = a.shape
+    N = w.shape[0]
+    p = GemmParams()
+    p.A, p.lda = ptr(a), a.stride(0)
+    p.W, p.ldw = ptr(w), w.stride(0)
+    p.C, p.ldc = ptr(v_out), v_out.stride(0)
+    p.M, p.N, p.K = M, N, Kd
+    p.epilogue = hip.EPI_QKV_ROPE
+    p.bias = ptr(bias)
+    p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sin), ptr(cos)
+    p.qkv_heads, p.qkv_head_dim, p.qkv_tokens, p.qkv_tokens_pad, p.qkv_prefix = heads, hd, tokens, tokens_pad, prefix
+    p.qkv_q_scale = q_scale
+    prof = KERNEL_TIMERS
+    timed = prof is not None and not torch.cuda.is_current_stream_capturing()
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
+    if rc == hip.ERR_UNSUPPORTED:
+        return False
+    check(rc, "gar_gemm(QKV_ROPE)")
+    if timed:
+        e1.record()
+        prof.append(("gemm_tile_bf16", 2.0 * M * N * Kd, (M * Kd + N * Kd + M * N) * a.element_size(), e0, e1))
+    return True
+
+
+def vit_v_transpose(v, Vt, T, N, H, hd, Npad):
+    check(lib().gar_vit_v_transpose(dtype_code(v.dtype), ptr(v), ptr(Vt), T, N, H, hd, Npad, stream()),
+          "gar_vit_v_transpose")
+
+
 def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale):
     check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vtc), B, S,
                                  Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), q_scale, stream()), "gar_llm_qkv_post")

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 1
+#define GAR_ABI_VERSION 2
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -46,6 +46,12 @@ extern "C" {
                                   /* C[:, N/2] = silu(gate) * up                             */
 #define GAR_EPI_PATCH_POS 6       /* row m -> tile m/tin, token tok_off + m%tin of a          */
                                   /* [tiles, tout, N] output; C = A W^T + pos[tok_off+m%tin] */
+#define GAR_EPI_QKV_ROPE 7        /* timm AttentionRope front half fused into the qkv GEMM (bf16 tile GEMM only):  */
+                                  /* v = A W^T + bias, columns [q | k | v] x [head][head_dim]; row m = token        */
+                                  /* m % qkv_tokens of image tile m / qkv_tokens. q, k: interleaved-pair RoPE for   */
+                                  /* tokens >= qkv_prefix (tables [tokens - prefix, head_dim] f32), q * qkv_q_scale, */
+                                  /* written to qkv_q / qkv_k [tiles, heads, qkv_tokens_pad, head_dim]; v written   */
+                                  /* row-major to C [M, heads*head_dim] (transposed later by gar_vit_v_transpose)   */
 
 typedef void* gar_stream_t;
 
@@ -68,6 +74,11 @@ typedef struct gar_gemm_params {
     float norm_eps;                    /* with norm_w: rsqrt(mean(x^2) + norm_eps)                  */
     const void* norm_w;                /* [K] or NULL; M <= 16 only: C = epilogue(RMSNorm(A; norm_w) W^T), i.e. the */
                                        /* HF LlamaRMSNorm in front of q/k/v, gate/up and lm_head fused into the GEMM */
+    /* GAR_EPI_QKV_ROPE only */
+    void* qkv_q; void* qkv_k;          /* [tiles, heads, qkv_tokens_pad, head_dim]                                   */
+    const float* qkv_sin; const float* qkv_cos;   /* [qkv_tokens - qkv_prefix, head_dim]                             */
+    int32_t qkv_heads, qkv_head_dim, qkv_tokens, qkv_tokens_pad, qkv_prefix;
+    float qkv_q_scale;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -99,6 +110,10 @@ int gar_rmsnorm(int dtype, const void* x, void* y, const void* w, int M, int D, 
  *   Q [T,H,Npad,hd], K [T,H,Npad,hd], Vt [T,H,hd,Npad]   (Vt pad columns zeroed). */
 int gar_vit_qkv_post(int dtype, const void* qkv, const float* sin, const float* cos, void* Q, void* K, void* Vt,
                      int T, int N, int npt, int H, int hd, int Npad, float q_scale, gar_stream_t stream);
+
+/* V third of gar_vit_qkv_post, for the fused GAR_EPI_QKV_ROPE GEMM: V [T*N, H*hd] row-major -> Vt [T, H, hd, Npad]
+ * (zero for tokens >= N). */
+int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T, int N, int H, int hd, int Npad, gar_stream_t stream);
 
 /* HF Llama pre-attention step on fused qkv [B*S, (Hq+2Hkv)*hd]: half-split RoPE (cos/sin [max_pos, hd/2] f32,
  * row = absolute position pos0+s), q scale folded, Q [B,Hq,Spad,hd]; K and V appended to the cache at

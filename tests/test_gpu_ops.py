@@ -512,3 +512,53 @@ def test_abi_errors_are_reported_not_thrown(dev):
     w = torch.zeros(16, 60, device=dev)
     with pytest.raises(hip.GarError, match="K=60"):
         ops.gemm(a, w, torch.zeros(4, 16, device=dev))
+
+
+@pytest.mark.parametrize("npt,hd,H", [(1, 64, 16), (0, 128, 8)])
+def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H):
+    """GAR_EPI_QKV_ROPE (q / k rotated, scaled and laid out by the qkv GEMM's epilogue + gar_vit_v_transpose) against the
+    two-kernel path (GAR_EPI_BIAS GEMM -> gar_vit_qkv_post) and against an fp64 statement; the fused path rounds to
+    bf16 once instead of twice, so the comparison is within bf16 rounding, not bitwise. Pad rows stay zero."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    T, n = 4, 1024
+    N = n + npt
+    D = H * hd
+    Npad = (N + 63) // 64 * 64
+    a = q(rnd(T * N, 256, seed=70), dt).to(dev, dt)
+    w = q(rnd(3 * D, 256, seed=71, scale=256 ** -0.5), dt).to(dev, dt)
+    b = q(rnd(3 * D, seed=72), dt).to(dev, dt)
+    sin = torch.sin(rnd(n, hd // 2, seed=73)).repeat_interleave(2, -1).contiguous().to(dev)
+    cos = torch.cos(rnd(n, hd // 2, seed=73)).repeat_interleave(2, -1).contiguous().to(dev)
+    qs = hd ** -0.5 * 1.4426950408889634
+    qkv = torch.empty(T * N, 3 * D, dtype=dt, device=dev)
+    Q0, K0 = (torch.zeros(T, H, Npad, hd, dtype=dt, device=dev) for _ in range(2))
+    V0 = torch.empty(T, H, hd, Npad, dtype=dt, device=dev)
+    ops.gemm(a, w, qkv, hip.EPI_BIAS, bias=b)
+    ops.vit_qkv_post(qkv, sin, cos, Q0, K0, V0, T, N, npt, H, hd, Npad, qs)
+    Q1, K1 = (torch.zeros(T, H, Npad, hd, dtype=dt, device=dev) for _ in range(2))
+    V1 = torch.full((T, H, hd, Npad), 7.0, dtype=dt, device=dev)
+    vrow = torch.empty(T * N, D, dtype=dt, device=dev)
+    assert ops.gemm_qkv_rope(a, w, b, vrow, Q1, K1, sin, cos, H, hd, N, Npad, npt, qs)
+    ops.vit_v_transpose(vrow, V1, T, N, H, hd, Npad)
+    # fp64 statement
+    full = (a.double() @ w.double().T + b.double()).view(T, N, 3, H, hd).cpu()
+    qr, kr, vr = full[:, :, 0], full[:, :, 1], full[:, :, 2]
+
+    def rope(x):
+        xr = x.clone()
+        body = x[:, npt:]
+        rot = torch.stack([-body[..., 1::2], body[..., 0::2]], -1).reshape(body.shape)
+        xr[:, npt:] = body * cos.cpu().double()[None, :, None, :] + rot * sin.cpu().double()[None, :, None, :]
+        return xr
+    qref = (rope(qr) * qs).permute(0, 2, 1, 3)
+    kref = rope(kr).permute(0, 2, 1, 3)
+    close(Q1[:, :, :N], qref, dt)
+    close(K1[:, :, :N], kref, dt)
+    close(V1[:, :, :, :N], vr.permute(0, 2, 3, 1), dt)
+    close(Q1, Q0.double().cpu(), dt)
+    close(K1, K0.double().cpu(), dt)
+    assert torch.equal(V1, V0)                              # v takes no arithmetic after the bias: identical
+    if Npad > N:
+        assert float(Q1[:, :, N:].abs().max()) == 0 and float(K1[:, :, N:].abs().max()) == 0
+        assert float(V1[:, :, :, N:].abs().max()) == 0
