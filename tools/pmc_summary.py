@@ -53,9 +53,9 @@ def main(fetch_csv, write_csv, out_json, read_scale=None):
         calib["WRITE_SIZE/expected(8B-per-lane writes)"] = wr[k][1] / (8.0 * wr[k][2])
     # our own streaming kernel with a known byte count: vit_qkv_post reads each qkv element once and writes it once
     # (16-B/lane loads and stores), so FETCH_SIZE / WRITE_SIZE should be 1.0 — 0.5 means FETCH_SIZE under-counts x2
-    k2 = "vit_qkv_post_kernel"
-    if k2 in rd and k2 in wr and wr[k2][1] > 0:
-        calib["FETCH_SIZE/WRITE_SIZE(vit_qkv_post: reads == writes)"] = rd[k2][1] / wr[k2][1]
+    for k2 in ("vit_qkv_post_kernel", "vit_v_transpose_kernel"):     # streaming relayout kernels: reads == writes
+        if k2 in rd and k2 in wr and wr[k2][1] > 0:
+            calib[f"FETCH_SIZE/WRITE_SIZE({k2}: reads == writes)"] = rd[k2][1] / wr[k2][1]
     scale = float(read_scale) if read_scale is not None else 1.0
     out = {"read_scale_applied": scale, "calibration(bf16_copy_kernel)": calib, "kernels": {}}
     for name in sorted(set(rd) | set(wr), key=lambda n: -(rd.get(n, [0, 0])[1] + wr.get(n, [0, 0])[1])):
