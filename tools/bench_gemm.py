@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Micro-benchmark of the bf16 GEMM kernels on the benchmark's shapes (random data, HIP-event timing).
-GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel."""
+GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel. Diagnostic rows: "nostore" = main loop
+only (epilogue skipped), "L2store" = every tile stores into the first tile's region (epilogue executed, no HBM write-back)
+— the decomposition quoted in DESIGN.md section 9."""
 import os
 import sys
 
@@ -16,7 +18,7 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
           ("llm gate/up", 37744, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 37744, 2048, 8192, hip.EPI_RES),
           ("square 8k", 8192, 8192, 8192, hip.EPI_NONE),
           ("proj none", 139400, 1024, 1024, hip.EPI_NONE), ("proj bias", 139400, 1024, 1024, hip.EPI_BIAS),
-          ("qkv nodephase", 139400, 3072, 1024, -2), ("proj nodephase", 139400, 1024, 1024, -2),
+          ("qkv L2store", 139400, 3072, 1024, -2), ("proj L2store", 139400, 1024, 1024, -2),
           ("proj nostore", 139400, 1024, 1024, -1), ("qkv nostore", 139400, 3072, 1024, -1),
           ("llm o nostore", 37744, 2048, 2048, -1)]
 
