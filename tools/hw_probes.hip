@@ -1,0 +1,104 @@
+// Sustained MFMA throughput and LDS read-rate probes (diagnostic, not part of the library): every wave issues independent
+// v_mfma_f32_16x16x32_bf16 back to back from registers only — the ceiling any GEMM main loop on this part sits under at
+// the clocks the chip actually holds.   hipcc --offload-arch=gfx950 -O3 tools/hw_probes.hip -o /tmp/hw_probes && /tmp/hw_probes
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a = {1, 2, 3, 4, 5, 6, 7, (short)threadIdx.x}, b = {8, 7, 6, 5, 4, 3, 2, (short)blockIdx.x};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 1.2345e30f) out[threadIdx.x] = s;
+}
+
+// LDS read rate: every wave streams conflict-free ds_read_b128 (lane-linear 1 KiB per instruction) out of a 64 KiB
+// region; bytes per clock per CU = what bounds the fragment reads of an LDS-staged GEMM.
+template <int PAT>
+__global__ __launch_bounds__(512) void lds_read_loop(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 16384; i += blockDim.x) reinterpret_cast<unsigned int*>(smem)[i] = i;
+    __syncthreads();
+    u32x4 acc = {0, 0, 0, 0};
+    // PAT 0: lane-linear; 1: MFMA A-fragment rows (row = lane & 15, 128-B rows), chunk (lane>>4) ^ (row & 7);
+    // 2: same rows, chunk (lane>>4) ^ ((row >> 1) & 7)
+    const int lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+    const int off = PAT == 0 ? lane * 16 : frow * 128 + ((fq ^ (PAT == 1 ? (frow & 7) : ((frow >> 1) & 7))) << 4);
+    const char* base = smem + off + (tid >> 6) * 8192;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + (PAT == 0 ? k * 1024 : (k >> 1) * 2048 + (k & 1) * 64));
+            acc ^= v;
+        }
+        asm volatile("" ::: "memory");
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[tid] = 1.f;
+}
+
+template <int PAT>
+static void run_lds(int waves, int cus, float* d) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_read_loop<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    lds_read_loop<PAT><<<cus, waves * 64, 65536>>>(d, 16);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    lds_read_loop<PAT><<<cus, waves * 64, 65536>>>(d, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)cus * waves * iters * 8 * 1024.0;
+    printf("ds_read_b128 pattern %d, %d waves per CU: %.3f ms  %.1f TB/s chip-wide = %.1f B/clk/CU at 2.1 GHz\n", PAT, waves, ms,
+           bytes / ms / 1e9, bytes / (ms * 1e-3) / cus / 2.1e9);
+}
+
+template <int NACC>
+static void run(const char* name, int blocks_per_cu, int cus, float* d) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    mfma_loop<NACC><<<cus * blocks_per_cu, 256>>>(d, 64);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        mfma_loop<NACC><<<cus * blocks_per_cu, 256>>>(d, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = 2.0 * 16 * 16 * 32 * (double)NACC * iters * 4.0 * cus * blocks_per_cu;
+        printf("%s, %d wave(s)/SIMD: %.3f ms  %.0f TFLOP/s\n", name, blocks_per_cu, ms, flop / ms / 1e9);
+    }
+}
+
+int main() {
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    float* d;
+    hipMalloc(&d, 4096);
+    run<16>("16 independent accumulators", 1, cus, d);
+    run<16>("16 independent accumulators", 2, cus, d);
+    run<4>("4 independent accumulators", 2, cus, d);
+    run_lds<0>(8, cus, d);
+    run_lds<1>(8, cus, d);
+    run_lds<2>(8, cus, d);
+    return 0;
+}
