@@ -7,15 +7,17 @@
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-template <int NACC>
+template <int NACC, int UNR>
 __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
     f32x4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 a = {1, 2, 3, 4, 5, 6, 7, (short)threadIdx.x}, b = {8, 7, 6, 5, 4, 3, 2, (short)blockIdx.x};
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += UNR) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll
@@ -69,17 +71,17 @@ static void run_lds(int waves, int cus, float* d) {
            bytes / ms / 1e9, bytes / (ms * 1e-3) / cus / 2.1e9);
 }
 
-template <int NACC>
+template <int NACC, int UNR>
 static void run(const char* name, int blocks_per_cu, int cus, float* d) {
     const int iters = 4096;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    mfma_loop<NACC><<<cus * blocks_per_cu, 256>>>(d, 64);
+    mfma_loop<NACC, UNR><<<cus * blocks_per_cu, 256>>>(d, 64);
     hipDeviceSynchronize();
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        mfma_loop<NACC><<<cus * blocks_per_cu, 256>>>(d, iters);
+        mfma_loop<NACC, UNR><<<cus * blocks_per_cu, 256>>>(d, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -94,9 +96,11 @@ int main() {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     float* d;
     hipMalloc(&d, 4096);
-    run<16>("16 independent accumulators", 1, cus, d);
-    run<16>("16 independent accumulators", 2, cus, d);
-    run<4>("4 independent accumulators", 2, cus, d);
+    run<16, 1>("16 independent accumulators", 1, cus, d);
+    run<16, 8>("16 independent accumulators, loop unrolled x8", 1, cus, d);
+    run<16, 1>("16 independent accumulators", 2, cus, d);
+    run<16, 8>("16 independent accumulators, loop unrolled x8", 2, cus, d);
+    run<4, 8>("4 independent accumulators, unrolled x8", 2, cus, d);
     run_lds<0>(8, cus, d);
     run_lds<1>(8, cus, d);
     run_lds<2>(8, cus, d);
