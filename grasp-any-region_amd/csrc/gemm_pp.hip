@@ -44,6 +44,13 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff
                                                  voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
 }
 
+// one of the two instructions of stage_half: i = 0 -> rows 8*wave .. +7, i = 1 -> rows 64 + 8*wave .. +7 of the 128-row half
+__device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base, char* lds,
+                                     int wave, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_AS(lds + (i * 8 + wave) * 1024), 16,
+                                             voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
+}
+
 template <int EPI, bool PERMT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
     constexpr bool PERM = PERMT && EPI != GAR_EPI_SWIGLU;
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     const int nt = p.K / PBK;
 
     f32x4 acc[8][4];
-    bf16x8 af[4][2], bq[2][2];        // current A sub-tile (4 m-tiles x 2 k-steps), current B sub-tile (2 n-tiles x 2)
+    bf16x8 af[4], bq[4];              // current A fragments (4 m-tiles of one half, one k-step), B fragments (4 n-tiles, one k-step)
 
     const unsigned rbA = (unsigned)p.lda * 2u, rbW = (unsigned)p.ldw * 2u;      // row pitch in bytes
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -103,32 +110,71 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     constexpr int BJ0 = PERM ? 4 * 128 : 16 * 128;      // byte step from n-tile 2q to 2q+1
     constexpr int BJ1 = 32 * 128;                       // byte step from n-tile pair q to q+1
 
-#define READ_A(st, mh)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-        af[i][0] = *reinterpret_cast<const bf16x8*>((st) + a_row + ((mh) * 4 + i) * 2048 + ca0);          \
-        af[i][1] = *reinterpret_cast<const bf16x8*>((st) + a_row + ((mh) * 4 + i) * 2048 + ca1);          \
-    }
-#define READ_B(st, nh)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-        bq[j][0] = *reinterpret_cast<const bf16x8*>((st) + b_row + (nh) * BJ1 + j * BJ0 + cb0);           \
-        bq[j][1] = *reinterpret_cast<const bf16x8*>((st) + b_row + (nh) * BJ1 + j * BJ0 + cb1);           \
-    }
-#define MMA(mh, nh)                                                                                      \
+#define READ_A(st, mh, kk)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        af[i] = *reinterpret_cast<const bf16x8*>(smem + ((st) ^ ((kk) ? 64 : 0)) + ((mh) * 4 + i) * 2048);
+#define READ_B(st, kk)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+        bq[j] = *reinterpret_cast<const bf16x8*>(smem + ((st) ^ ((kk) ? 64 : 0)) + (j >> 1) * BJ1 + (j & 1) * BJ0);
+#define MMA(mh)                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                       \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-                acc[(mh) * 4 + i][(nh) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
-                    bq[j][kk], af[i][kk], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+            acc[(mh) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[(mh) * 4 + i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);
-#define BAR_THEN_WAIT_LDS()                                  \
+#ifdef PP_TIMELINE   /* diagnostic build (tools/gemm_timeline.py): shader-clock stamps around every barrier */
+#if PP_TIMELINE >= 2   /* light: only the stamps around phase 0 (barriers 7 -> 0), so the other phases run undisturbed */
+#define TL(i) if ((i) == 15 || (i) <= 1 || (PP_TIMELINE == 3 && (i) >= 13)) tl[i] = (unsigned)__builtin_amdgcn_s_memtime();
+#define TLX(i) __builtin_amdgcn_sched_barrier(0); tl[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define TL(i) tl[i] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+#else
+#define TL(i)
+#endif
+#if PP_TIMELINE == 3
+#define TLX3(i) TLX(i)
+#else
+#define TLX3(i)
+#endif
+#if PP_TIMELINE >= 2
+#define TL_ACCUMULATE                                                                            \
+    tl_sum[0] += tl[0] - tl[15];              /* phase-0 loads */                                \
+    tl_sum[1] += tl[1] - tl[0];               /* wait at barrier 0 */                            \
+    tl_sum[15] += tl[15] - tl13p;             /* whole K tile (release of barrier 7 to the next) */ \
+    tl13p = tl[15];                                                                              \
+    if (PP_TIMELINE == 3) {                   /* previous K tile's phase-3 MFMA part (stamps lag one K tile) */ \
+        tl_sum[2] += tl2p - tl13q;            /* barrier 6 release -> 16 MFMAs issued */           \
+        tl_sum[3] += tl[3] - tl2p;            /* next K tile's address preparation */              \
+        tl_sum[4] += tl[14] - tl[3];          /* vmcnt wait */                                     \
+        tl_sum[5] += tl[15] - tl[14];         /* wait at barrier 7 */                              \
+        tl2p = tl[2]; tl13q = tl[13];                                                             \
+    }
+#elif defined(PP_TIMELINE)
+#define TL_ACCUMULATE                                                                            \
+    _Pragma("unroll") for (int q = 0; q < 7; ++q) {                                               \
+        tl_sum[2 * q] += tl[2 * q] - (q ? tl[2 * q - 1] : tl[15]);       /* work before barrier q */ \
+        tl_sum[2 * q + 1] += tl[2 * q + 1] - tl[2 * q];                  /* wait at barrier q */    \
+    }                                                                                            \
+    tl_sum[14] += tl[14] - tl13p;                                        /* barrier 7 of the previous K tile */ \
+    tl_sum[15] += tl[15] - tl[14];                                                               \
+    tl13p = tl[13];
+#else
+#define TL_ACCUMULATE
+#endif
+#define VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+#define BAR_THEN_WAIT_LDS(i)                                 \
     __builtin_amdgcn_sched_barrier(0);                       \
+    TL(2 * (i))                                              \
     __builtin_amdgcn_s_barrier();                            \
+    TL(2 * (i) + 1)                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
     __builtin_amdgcn_sched_barrier(0);
-#define BAR()                                                \
+#define BAR(i)                                               \
     __builtin_amdgcn_sched_barrier(0);                       \
+    TL(2 * (i))                                              \
     __builtin_amdgcn_s_barrier();                            \
+    TL(2 * (i) + 1)                                          \
     __builtin_amdgcn_sched_barrier(0);
 
     auto epilogue = [&]() {
@@ -301,6 +347,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         }
     };
 
+#ifdef PP_TIMELINE
+    unsigned tl[16], tl_sum[16], tl13p, tl2p = 0, tl13q = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tl_sum[q] = 0;
+    tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     int sidx = 0;
     while (true) {
 #pragma unroll
@@ -316,51 +368,153 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             m0n = tmn * PBM;
             n0n = tnn * PBM;
         }
-#pragma nounroll
-        for (int t = 0; t < nt; ++t) {
-            char* st = smem + sidx * PSTAGE;
-            char* nx = smem + (sidx ^ 1) * PSTAGE;
-            const bool last = t + 1 == nt;
-            const bool pf = !last || has_next;           // something to prefetch into the other stage
-            const int pm = last ? m0n : m0, pn = last ? n0n : n0, pt = last ? 0 : t + 1;
-            // ---- phase 0
-            READ_A(st, 0)
-            READ_B(st, 0)
-            if (pf) stage_A(pm, pt, nx);
-            BAR_THEN_WAIT_LDS()
-            MMA(0, 0)
-            BAR()
-            // ---- phase 1
-            READ_B(st, 1)
-            if (pf) stage_W(pn, pt, nx);
-            BAR_THEN_WAIT_LDS()
-            MMA(0, 1)
-            BAR()
-            // ---- phase 2
-            READ_A(st, 1)
-            BAR_THEN_WAIT_LDS()
-            MMA(1, 1)
-            BAR()
-            // ---- phase 3 (B0 is re-read: keeping both B sub-tiles live costs 16 VGPRs and spills — measured, no gain)
-            READ_B(st, 0)
-            if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 1: before the barrier both rows share
-            BAR_THEN_WAIT_LDS()
-            MMA(1, 0)
-            if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 0: same physical barrier
-            BAR()
-            sidx ^= 1;
+        // loop-carried, prepared at the end of the previous K tile under its last MFMAs (the first interval of a K tile is
+        // the longest: nothing but the reads and one DMA should sit between the barrier and the next barrier)
+        int ra = sidx * PSTAGE + a_row + ca0;                // this lane's A / W fragment rows (k-step 0 chunk) in the stage being read
+        int rb = sidx * PSTAGE + b_row + cb0;
+        char* nx = smem + (sidx ^ 1) * PSTAGE;               // stage being filled
+        unsigned bA, bW;                                     // global byte offsets of the K tile being prefetched
+        {
+            const bool last = nt == 1;
+            const int pm = last ? m0n : m0, pn = last ? n0n : n0, pt = last ? 0 : 1;
+            bA = (unsigned)pm * rbA + (unsigned)(pt * PBK * 2);
+            bW = (unsigned)pn * rbW + (unsigned)(pt * PBK * 2);
         }
+        // Four phases per K tile = (k-step, 64-row half of the wave's A rows): 8 + 4 + 8 + 4 fragment reads.
+        // The eight 1-KiB DMAs a wave issues per K tile go out 1 + 4 + 2 + 1 over the phases, ordered by when their 8-KiB
+        // unit (one instruction from each of the 8 waves) is first read in the next K tile:
+        //   W half 0 / 1, rows 0-63 / 64-127 (a b c d) and A half 0 rows 0-63 (e): row 0's phase 0
+        //   A half 1 rows 0-63 (f): row 1's phase 0 — one interval later;  A half 0 rows 64-127 (g): row 0's phase 1;
+        //   A half 1 rows 64-127 (h): row 1's phase 1.
+        // vmcnt retires in order, so "all but my newest n" names exactly the units that must have landed before the barrier
+        // ahead of each first read; the same counts are right for both rows (row 1 runs the same program one interval
+        // later, so the count its deadline needs is never looser than row 0's at the same program point).
+        // After the very last tile m0n = n0n = 0: a harmless prefetch nobody reads keeps the phases branch-free.
+#ifndef PP_SCHED
+#define PP_SCHED 0
+#endif
+#define DMA_A dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 0);
+#define DMA_B dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 1);
+#define DMA_C dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 0);
+#define DMA_D dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 1);
+#define DMA_E dma1(rsA, voffA, rbA, bA, nx, wave, 0);
+#define DMA_F dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
+#define DMA_G dma1(rsA, voffA, rbA, bA, nx, wave, 1);
+#define DMA_H dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
+#if PP_SCHED == 0        /* 1 4 2 1 */
+#define L0_DMA DMA_A
+#define L1_DMA DMA_B DMA_C DMA_D DMA_E
+#define L2_DMA DMA_F DMA_G
+#define L3_DMA DMA_H
+#define L0_WAIT VMWAIT(2)
+#define M0_WAIT VMWAIT(1)
+#elif PP_SCHED == 1      /* 1 5 2 0 */
+#define L0_DMA DMA_A
+#define L1_DMA DMA_B DMA_C DMA_D DMA_E DMA_F
+#define L2_DMA DMA_G DMA_H
+#define L3_DMA
+#define L0_WAIT VMWAIT(2)
+#define M0_WAIT VMWAIT(1)
+#else                    /* 0 5 2 1 */
+#define L0_DMA
+#define L1_DMA DMA_A DMA_B DMA_C DMA_D DMA_E
+#define L2_DMA DMA_F DMA_G
+#define L3_DMA DMA_H
+#define L0_WAIT VMWAIT(1)
+#define M0_WAIT VMWAIT(0)
+#endif
+#define PHASE012                                                                                                     \
+        /* ---- phase 0: k-step 0, rows 0-63 */                                                                      \
+        READ_A(ra, 0, 0)                                                                                             \
+        READ_B(rb, 0)                                                                                                \
+        L0_DMA                                                                                                       \
+        L0_WAIT                                                                /* g landed (row 0's phase-1 reads) */ \
+        BAR_THEN_WAIT_LDS(0)                                                                                         \
+        MMA(0)                                                                                                       \
+        M0_WAIT                                                                /* h landed (row 1's phase-1 reads) */ \
+        BAR(1)                                                                                                       \
+        /* ---- phase 1: k-step 0, rows 64-127 */                                                                    \
+        READ_A(ra, 1, 0)                                                                                             \
+        L1_DMA                                                                                                       \
+        BAR_THEN_WAIT_LDS(2)                                                                                         \
+        MMA(1)                                                                                                       \
+        BAR(3)                                                                                                       \
+        /* ---- phase 2: k-step 1, rows 0-63 */                                                                      \
+        READ_A(ra, 0, 1)                                                                                             \
+        READ_B(rb, 1)                                                                                                \
+        L2_DMA                                                                                                       \
+        BAR_THEN_WAIT_LDS(4)                                                                                         \
+        MMA(0)                                                                                                       \
+        BAR(5)
+        // phase 3 of K tile kt; under its MFMAs the addresses of K tile kt + 1 (whose prefetch is K tile kt + 2, wrapping into
+        // the next output tile) are prepared, so that nothing but reads and one DMA sits in the next phase 0
+#define PHASE3(kt)                                                                                                   \
+        /* ---- phase 3: k-step 1, rows 64-127 */                                                                    \
+        READ_A(ra, 1, 1)                                                                                             \
+        L3_DMA                                                                                                       \
+        VMWAIT(3)                                                              /* a-e landed (row 0's next phase 0) */ \
+        BAR_THEN_WAIT_LDS(6)                                                                                         \
+        /* the next K tile's addresses, issued between this phase's MFMAs (two scalar / vector ALU slots behind each) so  \
+           that nothing but reads and DMAs sits in the next phase 0; pinned so they are not re-derived behind the barrier */ \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        sidx ^= 1;                                                                                                   \
+        ra = sidx * PSTAGE + a_row + ca0;                                                                            \
+        rb = sidx * PSTAGE + b_row + cb0;                                                                            \
+        int nxo_ = (sidx ^ 1) * PSTAGE;                                                                              \
+        {                                                                                                            \
+            const bool last_ = (kt) + 2 >= nt;                                                                       \
+            const int pm_ = last_ ? m0n : m0, pn_ = last_ ? n0n : n0, pt_ = last_ ? 0 : (kt) + 2;                    \
+            bA = (unsigned)pm_ * rbA + (unsigned)(pt_ * PBK * 2);                                                    \
+            bW = (unsigned)pn_ * rbW + (unsigned)(pt_ * PBK * 2);                                                    \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[4 + i][j], 0, 0, 0);        \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                                                       \
+        }                                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        asm volatile("" : "+v"(ra), "+v"(rb), "+s"(nxo_), "+s"(bA), "+s"(bW));                                       \
+        nx = smem + nxo_;                                                                                            \
+        TLX3(2)                                                                                                      \
+        TL_ACCUMULATE                                                                                                \
+        TLX3(3)                                                                                                      \
+        VMWAIT(2)                                                              /* f landed (row 1's next phase 0) */ \
+        BAR(7)
+        // The K loop is rotated by one phase: a taken branch costs the wave ~150 cycles of instruction refetch (measured:
+        // tools/hw_probes.hip, tools/gemm_timeline.py), and phase 3's load interval (4 reads, 1 DMA) is the one with that
+        // much slack — phase 0's (8 reads behind the barrier that releases the stage) is the longest.
+        PHASE012
+#pragma nounroll
+        for (int t = 1; t < nt; ++t) {
+            PHASE3(t - 1)
+            PHASE012
+        }
+        PHASE3(nt - 1)
+#undef PHASE012
+#undef PHASE3
         // un-stagger (row 0 waits one interval for row 1), run the epilogue of (m0, n0) on both rows at the same time
         // — the next tile's first K tile is already in LDS, the stores drain under its main loop — then re-stagger.
         if (wm == 0) __builtin_amdgcn_s_barrier();
         if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
         else epilogue();
+#ifdef PP_TIMELINE
+        tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         if (!has_next) break;
         v = vn;
         m0 = m0n;
         n0 = n0n;
         if (wm == 1) __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (unused) prefetch must land before the LDS is released
+#ifdef PP_TIMELINE
+    if (p.tokens_in == -777 && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ((unsigned*)p.pos)[wave * 16 + q] = tl_sum[q];
+    }
+#endif
 #undef READ_A
 #undef READ_B
 #undef MMA

@@ -21,7 +21,7 @@ import torch
 
 from . import hip, ops
 from .configuration_gar import GARConfig
-from .weights import LM, PJ, VT, check_weights, load_weights, synthetic_weights
+from .weights import LM, PJ, VT, check_weights, load_weights, normalize_checkpoint, synthetic_weights
 
 LOG2E = 1.4426950408889634
 
@@ -91,7 +91,7 @@ class GARModel:
         import os
         if config is None:
             config = GARConfig.from_json_file(os.path.join(path, "config.json"))
-        return cls(config, load_weights(path), dtype, device)
+        return cls(config, normalize_checkpoint(config, load_weights(path)), dtype, device)
 
     @classmethod
     def from_shapes(cls, config: GARConfig, dtype=torch.bfloat16, device="cuda:0"):

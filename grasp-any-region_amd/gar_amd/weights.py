@@ -150,6 +150,53 @@ def load_weights(path: str) -> Dict[str, torch.Tensor]:
     return out
 
 
+def normalize_checkpoint(cfg, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Bring a checkpoint's tensors to the key layout of ``weight_shapes`` and fill the vision dimensions a HF
+    ``config.json`` leaves to the timm architecture defaults.
+
+    * ``vision_config.model_args`` of a released config only holds the overrides the reference itself reads
+      (``embed_dim``, ``img_size``, ``ref_feat_shape`` — configuration_gar.py:40-53, modeling_perception_lm.py:66);
+      ``depth`` and ``mlp_dim`` are taken from the tensors when absent (number of ``blocks.{i}`` groups, rows of
+      ``mlp.fc1.weight``) and checked against them when present;
+    * timm Eva attention stores the fused-qkv bias either as ``attn.qkv.bias`` or as ``attn.q_bias`` /
+      ``attn.v_bias`` (+ an optional ``attn.k_bias`` buffer, zero when missing), and un-fused checkpoints hold
+      ``attn.{q,k,v}_proj.{weight,bias}``: all are folded into ``attn.qkv.{weight,bias}``;
+    * tensors the path does not use (rotary buffers, heads, optimizer leftovers) are ignored.
+    Modifies ``cfg`` in place, returns a new dict; nothing is copied unless it has to be concatenated."""
+    import re
+    v = cfg.mllm_config.vision_config
+    W = dict(weights)
+    blocks = set()
+    pat = re.compile(re.escape(VT) + r"blocks\.(\d+)\.")
+    for k in W:
+        m = pat.match(k)
+        if m:
+            blocks.add(int(m.group(1)))
+    if blocks:
+        depth = max(blocks) + 1
+        if blocks != set(range(depth)):
+            raise KeyError(f"vision tower blocks are not contiguous: {sorted(blocks)[:8]}…")
+        if "depth" in v.model_args and int(v.model_args["depth"]) != depth:
+            raise ValueError(f"config says vision depth {v.model_args['depth']}, checkpoint holds {depth} blocks")
+        v.model_args["depth"] = depth
+        fc1 = W.get(f"{VT}blocks.0.mlp.fc1.weight")
+        if fc1 is not None:
+            if "mlp_dim" in v.model_args and int(v.model_args["mlp_dim"]) != fc1.shape[0]:
+                raise ValueError(f"config says vision mlp_dim {v.model_args['mlp_dim']}, checkpoint holds {fc1.shape[0]}")
+            v.model_args["mlp_dim"] = int(fc1.shape[0])
+        for i in range(depth):
+            a = f"{VT}blocks.{i}.attn."
+            if a + "qkv.weight" not in W and a + "q_proj.weight" in W:
+                W[a + "qkv.weight"] = torch.cat([W.pop(a + f"{n}_proj.weight") for n in "qkv"], dim=0)
+                if a + "q_proj.bias" in W:
+                    W[a + "qkv.bias"] = torch.cat([W.pop(a + f"{n}_proj.bias") for n in "qkv"], dim=0)
+            if a + "qkv.bias" not in W and a + "q_bias" in W:
+                qb, vb = W.pop(a + "q_bias"), W.pop(a + "v_bias")
+                kb = W.pop(a + "k_bias") if a + "k_bias" in W else torch.zeros_like(qb)
+                W[a + "qkv.bias"] = torch.cat([qb, kb, vb], dim=0)
+    return W
+
+
 def check_weights(cfg, weights: Dict[str, torch.Tensor]) -> None:
     """Loud failure on a key/shape mismatch (the loader contract of SURVEY.md §8f.1)."""
     shapes = weight_shapes(cfg)

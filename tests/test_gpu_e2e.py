@@ -393,3 +393,30 @@ def test_edge_cases_tiny(tiny):
                  aspect_ratios=torch.cat([sb["aspect_ratios"]] * 3))
     seq = mb.generate(**three, max_new_tokens=6).sequences
     assert torch.equal(seq[0], seq[1]) and torch.equal(seq[0], seq[2])
+
+
+@pytest.mark.parametrize("vision_bias", ["split", "unfused"])
+def test_from_pretrained_hf_style_sharded_checkpoint(tiny, tmp_path, vision_bias, hf_style_checkpoint):
+    """A checkpoint directory the way a release is laid out — config.json whose vision model_args only hold the
+    overrides the reference reads, safetensors shards, timm-Eva bias variants, unused tensors — loads through
+    GARModel.from_pretrained / GARProcessor.from_pretrained and generates the oracle's tokens."""
+    import json
+    from safetensors.torch import save_file
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    cfg, W, proc = tiny
+    ck, d = hf_style_checkpoint(cfg, W, vision_bias)
+    keys = sorted(ck)
+    for i in range(3):                                           # three shards, keys interleaved
+        save_file({k: ck[k].contiguous() for k in keys[i::3]}, str(tmp_path / f"model-{i + 1:05d}-of-00003.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(d))
+    m = GARModel.from_pretrained(str(tmp_path), torch.float32)
+    assert m.config.mllm_config.vision_config.depth == 2
+    p2 = GARProcessor.from_pretrained(str(tmp_path), m.config, max_num_tiles=4)
+    s = _sample(cfg, proc, 2)
+    s2 = _sample(m.config, p2, 2)
+    assert all(torch.equal(s[k], s2[k]) for k in ("pixel_values", "global_mask_values", "input_ids"))
+    assert s["bboxes"] == s2["bboxes"]
+    ref_seq, _ = _oracle(W, cfg, s, 8)
+    out = m.generate(**s2, max_new_tokens=8)
+    assert out.sequences.cpu().tolist() == ref_seq.tolist()

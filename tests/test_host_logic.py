@@ -154,6 +154,31 @@ def test_weights_naming_and_io(tmp_path):
     assert 1.5e9 < n1b < 1.6e9
 
 
+@pytest.mark.parametrize("vision_bias", ["split", "unfused"])
+def test_checkpoint_normalisation_fills_config_and_folds_bias_variants(vision_bias, hf_style_checkpoint):
+    from gar_amd.weights import normalize_checkpoint
+    cfg = GARConfig.tiny()
+    W = synthetic_weights(cfg)
+    ck, d = hf_style_checkpoint(cfg, W, vision_bias)
+    cfg2 = GARConfig.from_dict(json.loads(json.dumps(d)))
+    assert "depth" not in cfg2.mllm_config.vision_config.model_args
+    W2 = normalize_checkpoint(cfg2, ck)
+    v = cfg2.mllm_config.vision_config
+    assert (v.depth, v.mlp_dim) == (2, 256)
+    check_weights(cfg2, W2)
+    assert all(torch.equal(W[k], W2[k]) for k in W)
+    # a config that disagrees with the tensors is an error, not a silent reshape
+    cfg3 = GARConfig.tiny(**{"vision.depth": 3})
+    with pytest.raises(ValueError):
+        normalize_checkpoint(cfg3, ck)
+    # a missing k_bias buffer means zero (timm registers it non-persistent)
+    if vision_bias == "split":
+        ck = {k: t for k, t in ck.items() if not k.endswith("k_bias")}
+        W4 = normalize_checkpoint(GARConfig.from_dict(json.loads(json.dumps(d))), ck)
+        b = W4["mllm.model.vision_tower.timm_model.blocks.0.attn.qkv.bias"]
+        assert torch.count_nonzero(b[128:256]) == 0 and torch.equal(b[:128], W["mllm.model.vision_tower.timm_model.blocks.0.attn.qkv.bias"][:128])
+
+
 def test_resampling_tables_for_gpu_preprocessing():
     """tap tables used by the device preprocessing: weights reproduce torch's antialiased bicubic exactly (a resize
     done with the tables in numpy, sequential fma order, equals F.interpolate), NEAREST indices = floor(i * in/out)."""

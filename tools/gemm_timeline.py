@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Per-phase timeline of the ping-pong GEMM main loop (diagnostic). Needs a library built with
+`make EXTRA_gemm_pp=-DPP_TIMELINE`: block 0 accumulates, per wave, the shader-clock cycles spent working before and
+waiting at each of the eight barriers of a K tile (L0 M0 L1 M1 L2 M2 L3 M3; L = ds_reads + DMA issue, M = 16 MFMAs)
+and writes the sums through `pos` (tokens_in = -777). Prints cycles per K tile."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grasp-any-region_amd"))
+import torch  # noqa: E402
+
+from gar_amd import hip, ops  # noqa: E402
+
+
+def main():
+    hip.require_device(0)
+    dev = "cuda:0"
+    for name, M, N, K, nostore in [("proj", 139400, 1024, 1024, True), ("qkv", 139400, 3072, 1024, True),
+                                   ("llm down", 37744, 2048, 8192, True), ("qkv+store", 139400, 3072, 1024, False)]:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        dbg = torch.zeros(8 * 16, dtype=torch.int32, device=dev)
+        kw = dict(pos=dbg, tokens_in=-777)
+        if nostore:
+            kw["tokens_out"] = -12345
+        ops.gemm(a, w, out, hip.EPI_NONE, **kw)
+        torch.cuda.synchronize()
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        per_block = (tiles + 255) // 256                    # output tiles block 0 ran
+        ktiles = per_block * (K // 64)
+        d = dbg.cpu().view(8, 16).double() / ktiles
+        print(f"--- {name}: M={M} N={N} K={K}  block 0 ran {per_block} tiles = {ktiles} K tiles; cycles per K tile")
+        print("wave  " + "".join(f"{p + ('' if i % 2 == 0 else 'w'):>7s}" for p in
+                                  ("L0", "M0", "L1", "M1", "L2", "M2", "L3", "M3") for i in range(2)) + "    total")
+        for wv in range(8):
+            if os.environ.get("LIGHT"):          # -DPP_TIMELINE=2: only phase 0 and the whole K tile are stamped
+                print(f"  {wv}   L0 {float(d[wv][0]):6.0f}  L0w {float(d[wv][1]):6.0f}  K tile {float(d[wv][15]):6.0f}   "
+                      f"[-DPP_TIMELINE=3, phase 3 after barrier 6: 16 MFMAs issued {float(d[wv][2]):5.0f}, next-tile address "
+                      f"prep {float(d[wv][3]):5.0f}, vmcnt wait {float(d[wv][4]):5.0f}, wait at barrier 7 {float(d[wv][5]):5.0f}]")
+            else:
+                print(f"  {wv}   " + "".join(f"{x:7.0f}" for x in d[wv].tolist()) + f"  {float(d[wv].sum()):7.0f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,93 @@ static void run_lds(int waves, int cus, float* d) {
            bytes / ms / 1e9, bytes / (ms * 1e-3) / cus / 2.1e9);
 }
 
+
+// Interference probe: waves 0-3 (one per SIMD) stream independent MFMAs, waves 4-7 (their SIMD partners) run a side
+// stream until the MFMA waves are done: SIDE 0 nothing, 1 `buffer_load_dwordx4 ... lds` (1 KiB per instruction) from an
+// L2-resident buffer, 2 the same loads into registers, 3 conflict-free ds_read_b128, 4 DMA throttled by s_sleep.
+// Reports the MFMA rate and the side stream's rate: what a ping-pong GEMM's load row costs its MFMA row.
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+template <int SIDE>
+__global__ __launch_bounds__(512) void mixed_loop(float* out, const char* src, unsigned long long* side_ops, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    volatile int* flag = reinterpret_cast<volatile int*>(smem + 65536);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (wave < 4) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 a = {1, 2, 3, 4, 5, 6, 7, (short)threadIdx.x}, b = {8, 7, 6, 5, 4, 3, 2, (short)blockIdx.x};
+        __builtin_amdgcn_s_setprio(1);
+        for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        if (sum == 1.2345e30f) out[threadIdx.x] = sum;
+        if (wave == 0 && lane == 0) *flag = 1;
+        return;
+    }
+    unsigned long long n = 0;
+    if (SIDE == 0) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 20, 0x00020000);
+    const int voff = ((blockIdx.x & 15) << 16) + (wave - 4) * 8192 + lane * 16;
+    char* dst = smem + (wave - 4) * 16384;
+    u32x4 acc = {0, 0, 0, 0};
+    while (*flag == 0) {
+        if (SIDE == 1 || SIDE == 4) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_AS(dst + k * 1024), 16, voff + k * 1024, 0, 0, 0);
+                if (SIDE == 4) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (SIDE == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                acc ^= __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + voff + k * 1024));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc ^= *reinterpret_cast<const u32x4*>(dst + lane * 16 + k * 1024);
+            asm volatile("" ::: "memory");
+        }
+        n += 8;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[tid] = 1.f;
+    if (lane == 0) atomicAdd(side_ops, n);
+}
+
+template <int SIDE>
+static void run_mixed(const char* name, int cus, float* d, const char* src, unsigned long long* ops) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mixed_loop<SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64);
+    mixed_loop<SIDE><<<cus, 512, 65536 + 64>>>(d, src, ops, 64);
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(ops, 0, 8);
+    (void)hipEventRecord(e0);
+    mixed_loop<SIDE><<<cus, 512, 65536 + 64>>>(d, src, ops, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long n = 0;
+    (void)hipMemcpy(&n, ops, 8, hipMemcpyDeviceToHost);
+    const double flop = 2.0 * 16 * 16 * 32 * 16.0 * iters * 4.0 * cus;
+    printf("MFMA row + side stream [%s]: %.3f ms  MFMA %.0f TFLOP/s   side %.1f B/clk/CU at 2.1 GHz (%.2f KiB per 16 MFMAs per CU)\n",
+           name, ms, flop / ms / 1e9, (double)n * 1024.0 / (ms * 1e-3) / cus / 2.1e9,
+           (double)n / cus / (iters / 1.0));
+}
+
 template <int NACC, int UNR>
 static void run(const char* name, int blocks_per_cu, int cus, float* d) {
     const int iters = 4096;
@@ -101,6 +188,16 @@ int main() {
     run<16, 1>("16 independent accumulators", 2, cus, d);
     run<16, 8>("16 independent accumulators, loop unrolled x8", 2, cus, d);
     run<4, 8>("4 independent accumulators, unrolled x8", 2, cus, d);
+    char* src;
+    unsigned long long* ops;
+    hipMalloc(&src, 1 << 20);
+    hipMemset(src, 1, 1 << 20);
+    hipMalloc(&ops, 8);
+    run_mixed<0>("none", cus, d, src, ops);
+    run_mixed<1>("buffer_load ... lds", cus, d, src, ops);
+    run_mixed<4>("buffer_load ... lds, throttled", cus, d, src, ops);
+    run_mixed<2>("global_load_dwordx4 to registers", cus, d, src, ops);
+    run_mixed<3>("ds_read_b128", cus, d, src, ops);
     run_lds<0>(8, cus, d);
     run_lds<1>(8, cus, d);
     run_lds<2>(8, cus, d);
