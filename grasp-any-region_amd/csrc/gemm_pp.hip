@@ -6,20 +6,25 @@
 // while the other issues the ds_reads / global_load_lds of its next phase, so each SIMD's matrix pipe always has
 // exactly one wave feeding it and LDS / VMEM issue hides behind MFMAs.
 //
-//   K tile = 4 phases: (A0,B0) (B1) (A1) (B0)     A0/A1 = m-tiles 0-3 / 4-7 of the wave, B0/B1 = n-tiles 0-1 / 2-3
+//   K tile = 4 phases (k-step, 64-row half of the wave's A rows): 8 / 4 / 8 / 4 ds_read_b128 and 16 MFMAs each (no fragment
+//     is read twice; 32 VGPRs of fragments).
 //   staging: the next K tile (of this output tile, or K tile 0 of the NEXT output tile of the persistent loop) is
 //     DMA'd with `buffer_load_dwordx4 ... lds` (lane-linear LDS image, XOR swizzle applied to the SOURCE address,
-//     M / N tails zero-filled by the descriptor's bounds check) into the other stage during phase 0 (both A halves)
-//     and phase 1 (both W halves) — >= 2 intervals after the last ds_read of that stage (WAR) — and waited for with
-//     vmcnt(0) right before the last barrier of the K tile that both rows share, ~5 intervals after issue (RAW).
-//     The next output tile's first K tile is already in LDS when the epilogue starts.
+//     M / N tails zero-filled by the descriptor's bounds check) into the other stage, one 1-KiB instruction per wave per
+//     8-KiB unit, 1 + 4 + 2 + 1 instructions over the phases in the order the units are first read; vmcnt retires in order,
+//     so `s_waitcnt vmcnt(n)` = "all but my newest n" waits for exactly the units the next barrier releases (see the
+//     phase macros). The next output tile's first K tile is already in LDS when the epilogue starts.
+//   loop shape: the K loop is rotated by one phase so that its back-edge (a taken branch costs ~150 cycles of
+//     instruction refetch) sits in the short phase 3, and the next K tile's address arithmetic is issued between the MFMAs
+//     of phase 3 (sched_group_barrier) — phase 0, 8 reads right behind the barrier that releases the stage, is the longest.
 //   epilogue: the W rows of an n-tile pair are fed in a permuted order so that a lane ends up with EIGHT consecutive
 //     output columns; the fp32 accumulators go through the just-consumed LDS stage in four 64-row chunks and are read
 //     back row-wise, so bias / LayerScale / residual loads and the stores are 16-byte vectors covering 512
 //     contiguous bytes per row (SwiGLU and the PERM=0 variant store straight from the fragments).
-//   Measured limits (profiles/README.md): main loop 1.3-1.4 PFLOP/s; the epilogue is exposed
-//     (store issue back-pressures at ~0.4 TB/s of L2 write-back per XCD and gfx9's in-order vmcnt ties the next
-//     tile's DMA waits to the outstanding stores).
+//   Measured (tools/gemm_timeline.py with -DPP_TIMELINE=n builds, tools/bench_gemm.py): main loop
+//     1.45-1.59 PFLOP/s at a shader clock that the power limit holds at 1.4-1.65 GHz under this load (s_memtime ticks
+//     per wall second), i.e. ~0.9 of the matrix pipes' rate at that clock; the epilogue costs ~21k clocks per 256 x 256
+//     tile whatever the stores hit (HBM or one L2-resident tile).
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
@@ -132,6 +137,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #else
 #define TL(i)
 #endif
+#if PP_TIMELINE == 4     /* K-tile durations by position inside an output tile (0, 1, 2, 3, later) + epilogue */
+#define TL_ACC4(kt)                                                                              \
+    if ((kt) >= 1) {                                                                             \
+        const unsigned d_ = tl[15] - tl13p;                                                      \
+        const int b_ = (kt) - 1 < 4 ? (kt) - 1 : 4;                                              \
+        tl_sum[8] += b_ == 0 ? d_ : 0; tl_sum[9] += b_ == 1 ? d_ : 0; tl_sum[10] += b_ == 2 ? d_ : 0; \
+        tl_sum[11] += b_ == 3 ? d_ : 0; tl_sum[12] += b_ == 4 ? d_ : 0;                           \
+    }
+#else
+#define TL_ACC4(kt)
+#endif
 #if PP_TIMELINE == 3
 #define TLX3(i) TLX(i)
 #else
@@ -177,6 +193,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     TL(2 * (i) + 1)                                          \
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef PP_TIMELINE
+    unsigned tl[16], tl_sum[16], tl13p, tl2p = 0, tl13q = 0, tl_e = 0;
+    const unsigned long long tl_start = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tl_sum[q] = 0;
+    tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     auto epilogue = [&]() {
         if (p.tokens_out == -12345) {       // DEBUG (tools/bench_gemm.py only): skip the epilogue, keep acc live
 #pragma unroll
@@ -230,12 +253,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     // 16-byte chunks), then ALL eight waves read whole rows back and run bias / LayerScale / residual / store on
     // 8-column groups: every global access of a wave instruction is 2 rows x 512 contiguous bytes.
     // Called with both wave rows aligned; 2 barriers per 64-row chunk.
+#if PP_TIMELINE == 5   /* epilogue: per 64-row chunk [aux loads + LDS write | barrier | LDS read + math + stores | barrier] */
+#define EPI_TL(i) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tl_sum[i] += t_ - tl_e; tl_e = t_; }
+#else
+#define EPI_TL(i)
+#endif
     auto epilogue_lds = [&](char* E) {
         constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;
         constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES || QKV;
         constexpr bool HAS_RES = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES;
         // a thread always serves the same 8-column group (cg = tid & 31): bias / LayerScale are loaded once per tile
-        const int cg = tid & 31, r0 = tid >> 5;
+        // (opaque per call: otherwise the compiler hoists the sixteen 64-bit row addresses and the LDS offsets out of the
+        // persistent tile loop, spills them, and reloads each one behind an s_waitcnt vmcnt(0) — i.e. behind the previous store)
+        int cg = tid & 31, r0 = tid >> 5, frow_e = frow, fq_e = fq;
+        asm volatile("" : "+v"(cg), "+v"(r0), "+v"(frow_e), "+v"(fq_e));
         const int n = n0 + cg * 8;
         const bool nok = n < p.N;
         float bias8[8], gam8[8];
@@ -246,6 +277,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
         if (HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
+        auto write_chunk = [&](int c) {        // the owning wave row's fragments of 64-row chunk c -> E (fp32)
+            if (wm == (c >> 1)) {
+#pragma unroll
+                for (int il = 0; il < 4; ++il) {
+                    const int i = (c & 1) * 4 + il;
+                    const int row = il * 16 + frow_e;
+                    char* rp = E + row * 1024;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int chunk = wn * 16 + (j >> 1) * 8 + fq_e * 2 + (j & 1);
+                        *reinterpret_cast<f32x4*>(rp + ((chunk ^ (frow_e & 15)) << 4)) = acc[i][j];
+                    }
+                }
+            }
+        };
+        // Pipelined over the four chunks: [read chunk c back into registers] barrier [write chunk c+1 | math + stores of
+        // chunk c] barrier. The stores of a chunk are issued against the chip-wide write rate (all CUs reach their
+        // epilogues together), so the LDS hand-over of the next chunk runs under that back-pressure instead of after it.
+        write_chunk(0);
+        EPI_TL(0) __builtin_amdgcn_s_barrier(); EPI_TL(1)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // issue this chunk's row-dependent loads (residual / pos-embed) before waiting for the LDS hand-over
@@ -268,26 +319,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         aux[k] = *reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + n);
                 }
             }
-            if (wm == (c >> 1)) {
-#pragma unroll
-                for (int il = 0; il < 4; ++il) {
-                    const int i = (c & 1) * 4 + il;
-                    const int row = il * 16 + frow;
-                    char* rp = E + row * 1024;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int chunk = wn * 16 + (j >> 1) * 8 + fq * 2 + (j & 1);
-                        *reinterpret_cast<f32x4*>(rp + ((chunk ^ (frow & 7)) << 4)) = acc[i][j];
-                    }
-                }
-            }
-            __builtin_amdgcn_s_barrier();
+            f32x4 ra4[4], rb4[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = k * 16 + r0;
                 const char* rp = E + row * 1024;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rp + (((cg * 2) ^ (row & 7)) << 4));
-                const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((cg * 2 + 1) ^ (row & 7)) << 4));
+                ra4[k] = *reinterpret_cast<const f32x4*>(rp + (((cg * 2) ^ (row & 15)) << 4));
+                rb4[k] = *reinterpret_cast<const f32x4*>(rp + (((cg * 2 + 1) ^ (row & 15)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            EPI_TL(2) __builtin_amdgcn_s_barrier(); EPI_TL(3)
+            if (c < 3) write_chunk(c + 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 a = ra4[k], b = rb4[k];
                 if (ok[k]) {
                     float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                     if (HAS_BIAS) {
@@ -343,16 +388,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                     }
                 }
             }
-            __builtin_amdgcn_s_barrier();
+            if (c < 3) { EPI_TL(0) __builtin_amdgcn_s_barrier(); EPI_TL(1) }
         }
     };
 
-#ifdef PP_TIMELINE
-    unsigned tl[16], tl_sum[16], tl13p, tl2p = 0, tl13q = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tl_sum[q] = 0;
-    tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
     int sidx = 0;
     while (true) {
 #pragma unroll
@@ -390,9 +429,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // ahead of each first read; the same counts are right for both rows (row 1 runs the same program one interval
         // later, so the count its deadline needs is never looser than row 0's at the same program point).
         // After the very last tile m0n = n0n = 0: a harmless prefetch nobody reads keeps the phases branch-free.
-#ifndef PP_SCHED
-#define PP_SCHED 0
-#endif
 #define DMA_A dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 0);
 #define DMA_B dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 1);
 #define DMA_C dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 0);
@@ -401,28 +437,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #define DMA_F dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
 #define DMA_G dma1(rsA, voffA, rbA, bA, nx, wave, 1);
 #define DMA_H dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
-#if PP_SCHED == 0        /* 1 4 2 1 */
+// 1 + 4 + 2 + 1 (1 5 2 0 and 0 5 2 1 measured within noise of it)
 #define L0_DMA DMA_A
 #define L1_DMA DMA_B DMA_C DMA_D DMA_E
 #define L2_DMA DMA_F DMA_G
 #define L3_DMA DMA_H
 #define L0_WAIT VMWAIT(2)
 #define M0_WAIT VMWAIT(1)
-#elif PP_SCHED == 1      /* 1 5 2 0 */
-#define L0_DMA DMA_A
-#define L1_DMA DMA_B DMA_C DMA_D DMA_E DMA_F
-#define L2_DMA DMA_G DMA_H
-#define L3_DMA
-#define L0_WAIT VMWAIT(2)
-#define M0_WAIT VMWAIT(1)
-#else                    /* 0 5 2 1 */
-#define L0_DMA
-#define L1_DMA DMA_A DMA_B DMA_C DMA_D DMA_E
-#define L2_DMA DMA_F DMA_G
-#define L3_DMA DMA_H
-#define L0_WAIT VMWAIT(1)
-#define M0_WAIT VMWAIT(0)
-#endif
 #define PHASE012                                                                                                     \
         /* ---- phase 0: k-step 0, rows 0-63 */                                                                      \
         READ_A(ra, 0, 0)                                                                                             \
@@ -478,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         asm volatile("" : "+v"(ra), "+v"(rb), "+s"(nxo_), "+s"(bA), "+s"(bW));                                       \
         nx = smem + nxo_;                                                                                            \
         TLX3(2)                                                                                                      \
+        TL_ACC4(kt)                                                                                                  \
         TL_ACCUMULATE                                                                                                \
         TLX3(3)                                                                                                      \
         VMWAIT(2)                                                              /* f landed (row 1's next phase 0) */ \
@@ -496,9 +518,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #undef PHASE3
         // un-stagger (row 0 waits one interval for row 1), run the epilogue of (m0, n0) on both rows at the same time
         // — the next tile's first K tile is already in LDS, the stores drain under its main loop — then re-stagger.
+#if PP_TIMELINE == 5
+        tl_e = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+#if PP_TIMELINE == 4
+        const unsigned tl_e0 = (unsigned)__builtin_amdgcn_s_memtime();
+        tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
+#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();
         if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
         else epilogue();
+#if PP_TIMELINE == 4
+        tl_sum[13] += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;          // un-stagger + epilogue
+#endif
 #ifdef PP_TIMELINE
         tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
@@ -513,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     if (p.tokens_in == -777 && blockIdx.x == 0 && lane == 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) ((unsigned*)p.pos)[wave * 16 + q] = tl_sum[q];
+        if (wave == 0) ((unsigned*)p.pos)[128] = (unsigned)(__builtin_amdgcn_s_memtime() - tl_start);      // whole kernel, block 0
     }
 #endif
 #undef READ_A

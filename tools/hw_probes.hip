@@ -158,6 +158,92 @@ static void run_mixed(const char* name, int cus, float* d, const char* src, unsi
            (double)n / cus / (iters / 1.0));
 }
 
+// Store-rate probe: one 512-thread block per CU, every wave streams 16-byte-per-lane stores (1 KiB per instruction,
+// 2 rows x 512 contiguous bytes like the GEMM epilogue) into its own region. MODE 0 plain, 1 nt, 2 sc0 sc1, 3 sc0 sc1 nt;
+// `span` bytes per CU are cycled (span = 128 KiB: L2-resident target; large: streams to HBM).
+template <int MODE>
+__global__ __launch_bounds__(512) void store_loop(char* dst, size_t span, int iters) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const int tid = threadIdx.x;
+    char* base = dst + (size_t)blockIdx.x * span;
+    u32x4 v = {1u, 2u, 3u, (unsigned)tid};
+    size_t off = (size_t)tid * 16;
+    for (int it = 0; it < iters; ++it) {
+        char* ptr = base + off;
+        if (MODE == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+        if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+        if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+        if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(ptr), "v"(v) : "memory");
+        off += 8192;
+        if (off >= span) off = (size_t)tid * 16;
+    }
+}
+
+template <int MODE>
+static void run_store(const char* name, int cus, int blocks, char* buf, size_t span) {
+    const int iters = 2048;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    store_loop<MODE><<<blocks, 512>>>(buf, span, 64);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    store_loop<MODE><<<blocks, 512>>>(buf, span, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)blocks * iters * 8192.0;
+    printf("stores [%s], %d blocks, %zu KiB per block: %.3f ms  %.2f TB/s chip-wide = %.1f GB/s per block\n", name, blocks,
+           span >> 10, ms, bytes / ms / 1e9, bytes / ms / 1e6 / blocks);
+}
+
+// The GEMM epilogue's store pattern in isolation: persistent blocks walk 256x256 bf16 tiles of a row-major M x N matrix
+// in the kernel's tile order (8 m-tiles x all n-tiles per group, XCD-contiguous), each wave instruction writes 2 rows x
+// 512 B. ORDER 0: the kernel's order; 1: n-fastest inside a group.
+template <int ORDER>
+__global__ __launch_bounds__(512) void tile_store_loop(char* dst, int M, int N, int reps) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    const int tid = threadIdx.x, cg = tid & 31, r0 = tid >> 5;
+    const int tiles_m = (M + 255) / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
+    const u32x4 val = {1u, 2u, 3u, (unsigned)tid};
+    for (int rep = 0; rep < reps; ++rep)
+        for (int v = blockIdx.x; v < total; v += gridDim.x) {
+            const int q = total >> 3, r = total & 7, xcd = v & 7;
+            const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+            const int gsz = 8 * tiles_n, g = wg / gsz, first_m = g * 8;
+            const int gm = min(tiles_m - first_m, 8), in = wg - g * gsz;
+            const int tm = ORDER == 0 ? first_m + in % gm : first_m + in / tiles_n;
+            const int tn = ORDER == 0 ? in / gm : in % tiles_n;
+            for (int c = 0; c < 4; ++c)
+                for (int k = 0; k < 4; ++k) {
+                    const int m = tm * 256 + c * 64 + k * 16 + r0;
+                    if (m < M) {
+                        char* ptr = dst + ((size_t)m * N + tn * 256 + cg * 8) * 2;
+                        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(val) : "memory");
+                    }
+                }
+        }
+}
+
+template <int ORDER>
+static void run_tile_store(int cus, char* buf, int M, int N) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    tile_store_loop<ORDER><<<cus, 512>>>(buf, M, N, 1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    tile_store_loop<ORDER><<<cus, 512>>>(buf, M, N, 4);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = 4.0 * M * N * 2.0;
+    printf("tile stores (GEMM epilogue pattern, order %d) M=%d N=%d: %.3f ms per pass  %.2f TB/s = %.1f GB/s per CU\n", ORDER, M, N,
+           ms / 4, bytes / ms / 1e9, bytes / ms / 1e6 / cus);
+}
+
 template <int NACC, int UNR>
 static void run(const char* name, int blocks_per_cu, int cus, float* d) {
     const int iters = 4096;
@@ -198,6 +284,24 @@ int main() {
     run_mixed<4>("buffer_load ... lds, throttled", cus, d, src, ops);
     run_mixed<2>("global_load_dwordx4 to registers", cus, d, src, ops);
     run_mixed<3>("ds_read_b128", cus, d, src, ops);
+    {
+        char* big;
+        const size_t span_hbm = 16u << 20;
+        hipMalloc(&big, (size_t)cus * span_hbm);
+        for (int blocks : {cus, cus / 2, cus / 8, 8}) {
+            run_store<0>("plain, HBM", cus, blocks, big, span_hbm);
+            run_store<1>("nt, HBM", cus, blocks, big, span_hbm);
+            run_store<2>("sc0 sc1, HBM", cus, blocks, big, span_hbm);
+            run_store<3>("sc0 sc1 nt, HBM", cus, blocks, big, span_hbm);
+        }
+        run_store<0>("plain, L2-resident", cus, cus, big, 128u << 10);
+        run_store<1>("nt, L2-resident", cus, cus, big, 128u << 10);
+        for (int N : {1024, 3072, 4096, 2048}) {
+            run_tile_store<0>(cus, big, 139400, N);
+            run_tile_store<1>(cus, big, 139400, N);
+        }
+        hipFree(big);
+    }
     run_lds<0>(8, cus, d);
     run_lds<1>(8, cus, d);
     run_lds<2>(8, cus, d);
