@@ -15,15 +15,15 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned int)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even, NaN quieted: gfx950's v_cvt_pk_bf16_f32 (the integer formulation costs ~10
+// instructions per element, four of them exec-mask juggling for the NaN case — it dominated the GEMM epilogue)
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    const f32x2_hw_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_hw_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct DT;
 template <> struct DT<float> {
