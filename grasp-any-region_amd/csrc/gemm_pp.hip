@@ -392,6 +392,77 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         }
     };
 
+    // bf16-staged epilogue for outputs that are a function of the accumulator and its column only (none / bias / bias +
+    // gelu): the math runs on the fragments, the rounded bf16 tile goes through the consumed stage in two 128-row halves
+    // (one per wave row, 64 KiB each), and the read-back is a plain 16-byte copy — half the LDS bytes, no conversion on the
+    // store side, three barriers per tile instead of eight. Same arithmetic and rounding as the fp32-staged path.
+    auto epilogue_lds_bf16 = [&](char* E) {
+        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
+        int cg = tid & 31, r0 = tid >> 5, frow_e = frow, fq_e = fq;
+        asm volatile("" : "+v"(cg), "+v"(r0), "+v"(frow_e), "+v"(fq_e));       // see epilogue_lds
+        u32x4 biasp[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};      // kept packed: 8 VGPRs instead of 16 next to 128 accumulators
+        if (HAS_BIAS) {
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                const int nb = n0 + wn * 64 + jq * 32 + fq_e * 8;
+                if (nb < p.N) biasp[jq] = *reinterpret_cast<const u32x4*>((const bf16_t*)p.bias + nb);
+            }
+        }
+        auto write_half = [&](int c) {
+            if (wm == c) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    char* rp = E + (i * 16 + frow_e) * 512;
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
+                                      acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
+                        if (HAS_BIAS) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o[2 * e] += __uint_as_float(biasp[jq][e] << 16);
+                                o[2 * e + 1] += __uint_as_float(biasp[jq][e] & 0xffff0000u);
+                            }
+                        }
+                        if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
+                        }
+                        const int c16 = wn * 8 + jq * 4 + fq_e;
+                        *reinterpret_cast<u32x4*>(rp + ((c16 ^ (frow_e & 15)) << 4)) =
+                            u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                    }
+                }
+            }
+        };
+        const int n = n0 + cg * 8;
+        const bool nok = n < p.N;
+        write_half(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = k * 16 + r0;
+                v[k] = *reinterpret_cast<const u32x4*>(E + row * 512 + ((cg ^ (row & 15)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c == 0) write_half(1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ml = c * 128 + k * 16 + r0;
+                if (nok && m0 + ml < p.M) {
+                    const int64_t off = p.tokens_out == -12346 ? (int64_t)ml * p.ldc + (n - n0)      // DEBUG: L2-resident stores
+                                                                : (int64_t)(m0 + ml) * p.ldc + n;
+                    *reinterpret_cast<u32x4*>((bf16_t*)p.C + off) = v[k];
+                }
+            }
+            if (c == 0) __builtin_amdgcn_s_barrier();
+        }
+    };
+
     int sidx = 0;
     while (true) {
 #pragma unroll
@@ -526,7 +597,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
         if (wm == 0) __builtin_amdgcn_s_barrier();
-        if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+        constexpr bool BF16_STAGE = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
+        if (PERM && LDS_EPI && BF16_STAGE && p.tokens_out != -12345) epilogue_lds_bf16(smem + (sidx ^ 1) * PSTAGE);
+        else if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
         else epilogue();
 #if PP_TIMELINE == 4
         tl_sum[13] += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;          // un-stagger + epilogue
