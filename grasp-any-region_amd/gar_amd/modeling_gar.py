@@ -79,7 +79,8 @@ class GARModel:
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
         self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
-        self.prefill_chunk = 16      # regions per vision-tower / prefill pass (decode serves all B at once)
+        # regions per vision-tower / prefill pass (decode serves all B at once)
+        self.prefill_chunk = int(os.environ.get("GAR_PREFILL_CHUNK", "16"))
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod

@@ -59,10 +59,13 @@ def test_gemm_plain_and_tails(dev, dt, M, N, K):
     assert float((out[:, N:].float() - 7.0).abs().max()) == 0 if ldc > N else True
 
 
-@pytest.mark.parametrize("M,N,K", [(4099, 2048, 192), (8192, 1024, 64), (2049, 4096, 1024), (5000, 1968, 128)])
+@pytest.mark.parametrize("M,N,K", [(4099, 2048, 192), (8192, 1024, 64), (2049, 4096, 1024), (5000, 1968, 128),
+                                   (16640, 2048, 64), (9000, 2048, 128), (33000, 1024, 320)])
 def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
-    """shapes large enough (>= 128 tiles of 256x256) to take the ping-pong kernel, incl. M / N tails and every
-    epilogue; compared element-wise with an fp64 reference of the same bf16 inputs."""
+    """shapes large enough (>= 128 tiles of 256x256) to take the ping-pong kernel, incl. M / N tails, every epilogue,
+    one / two / odd numbers of K tiles and more tiles than CUs (the persistent loop's prefetch wraps into the next
+    output tile at every position of the rotated K loop); compared element-wise with an fp64 reference of the same
+    bf16 inputs."""
     from gar_amd import hip, ops
     dt = torch.bfloat16
     a, w = q(rnd(M, K, seed=50), dt), q(rnd(N, K, seed=51, scale=K ** -0.5), dt)
@@ -74,6 +77,11 @@ def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
     bias, gamma, res = q(rnd(N, seed=52), dt), q(rnd(N, seed=53), dt), q(rnd(M, N, seed=54), dt)
     ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=bias.to(dev, dt))
     close(out, F.gelu(acc + bias.double()), dt)
+    ops.gemm(A, W_, out, hip.EPI_BIAS, bias=bias.to(dev, dt))
+    close(out, acc + bias.double(), dt)
+    r = res.to(dev, dt).clone()
+    ops.gemm(A, W_, r, hip.EPI_RES, residual=r)
+    close(r, res.double() + acc, dt)
     r = res.to(dev, dt).clone()
     ops.gemm(A, W_, r, hip.EPI_BIAS_SCALE_RES, bias=bias.to(dev, dt), residual=r, gamma=gamma.to(dev, dt))
     close(r, res.double() + gamma.double() * (acc + bias.double()), dt)
@@ -100,6 +108,11 @@ def test_gemm_epilogues(dev, dt, M):
     close(out, acc + bias.double(), dt)
     ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=bias.to(dev, dt))
     close(out, F.gelu(acc + bias.double()), dt)
+    ops.gemm(A, W_, out, hip.EPI_BIAS, bias=bias.to(dev, dt))
+    close(out, acc + bias.double(), dt)
+    r = res.to(dev, dt).clone()
+    ops.gemm(A, W_, r, hip.EPI_RES, residual=r)
+    close(r, res.double() + acc, dt)
     r = res.to(dev, dt).clone()
     ops.gemm(A, W_, r, hip.EPI_BIAS_SCALE_RES, bias=bias.to(dev, dt), residual=r, gamma=gamma.to(dev, dt))   # in place
     close(r, res.double() + gamma.double() * (acc + bias.double()), dt)
