@@ -392,74 +392,152 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         }
     };
 
-    // bf16-staged epilogue for outputs that are a function of the accumulator and its column only (none / bias / bias +
-    // gelu): the math runs on the fragments, the rounded bf16 tile goes through the consumed stage in two 128-row halves
-    // (one per wave row, 64 KiB each), and the read-back is a plain 16-byte copy — half the LDS bytes, no conversion on the
-    // store side, three barriers per tile instead of eight. Same arithmetic and rounding as the fp32-staged path.
-    auto epilogue_lds_bf16 = [&](char* E) {
-        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
-        int cg = tid & 31, r0 = tid >> 5, frow_e = frow, fq_e = fq;
-        asm volatile("" : "+v"(cg), "+v"(r0), "+v"(frow_e), "+v"(fq_e));       // see epilogue_lds
-        u32x4 biasp[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};      // kept packed: 8 VGPRs instead of 16 next to 128 accumulators
-        if (HAS_BIAS) {
+    // Barrier-free per-wave epilogue (none / bias / gelu / residual / LayerScale / pos-embed outputs): every wave turns its
+    // own 128 x 64 strip from MFMA fragments into rows through a PRIVATE 4-KiB piece of the consumed stage — its wave
+    // row's A half, which only that row ever reads — 16 rows at a time, and stores 8 rows x 128 contiguous bytes per
+    // instruction. No workgroup barrier, no cross-wave hand-over: the eight waves run their LDS / ALU / store streams
+    // independently, and wave row 0's un-stagger barrier sits after its first 16 rows instead of in front of idle time.
+    // DIRECT outputs (a function of accumulator and column only) are rounded on the fragments and staged as bf16; the
+    // others are staged in fp32 and finished on the row side, with the row-dependent loads (residual / pos-embed)
+    // issued two 16-row steps ahead: vmcnt retires in order, so a load issued behind a store waits for that store's ack.
+    auto epilogue_wave = [&](char* E) {
+        constexpr bool DIRECT = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
+        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES;
+        constexpr bool HAS_AUX = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES || EPI == GAR_EPI_PATCH_POS;
+        int lane_e = lane, frow_e = frow, fq_e = fq;
+        asm volatile("" : "+v"(lane_e), "+v"(frow_e), "+v"(fq_e));             // see epilogue_lds
+        char* priv = E + wm * PHALF + wn * 4096;
+        const int rr = lane_e >> 3, ch = lane_e & 7;      // row side: rows rr and 8 + rr of a 16-row step, 8 columns ch*8..
+        const int n = n0 + wn * 64 + ch * 8;
+        const bool nok = n < p.N;
+        u32x4 biasp[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};      // DIRECT: this lane's fragment columns
+        float bias8[8], gam8[8];                                              // otherwise: this lane's row-side columns
+        if (DIRECT && HAS_BIAS) {
 #pragma unroll
             for (int jq = 0; jq < 2; ++jq) {
                 const int nb = n0 + wn * 64 + jq * 32 + fq_e * 8;
                 if (nb < p.N) biasp[jq] = *reinterpret_cast<const u32x4*>((const bf16_t*)p.bias + nb);
             }
         }
-        auto write_half = [&](int c) {
-            if (wm == c) {
+        if (!DIRECT && HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
+        if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
+        // destination element offset and row-dependent load of row-side slot (i, t)
+        auto row_of = [&](int i, int t) { return m0 + wm * 128 + i * 16 + t * 8 + rr; };
+        auto dst_off = [&](int m) -> int64_t {
+            if (EPI == GAR_EPI_PATCH_POS) {
+                const int tile = m / p.tokens_in;
+                return ((int64_t)tile * p.tokens_out + p.token_offset + (m - tile * p.tokens_in)) * p.ldc + n;
+            }
+            if (p.tokens_out == -12346) return (int64_t)(m - m0) * p.ldc + (n - n0);     // DEBUG: L2-resident stores
+            return (int64_t)m * p.ldc + n;
+        };
+        auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional (clamped) so the prefetch ring carries no exec state
+            const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
+            if (EPI == GAR_EPI_PATCH_POS) {
+                const int tile = m / p.tokens_in;
+                const int tok = p.token_offset + (m - tile * p.tokens_in);
+                return *reinterpret_cast<const u32x4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + nc);
+            }
+            return *reinterpret_cast<const u32x4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + nc);
+        };
+        u32x4 aux[3][2];
+        if (HAS_AUX) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    char* rp = E + (i * 16 + frow_e) * 512;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jq = 0; jq < 2; ++jq) {
-                        float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
-                                      acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
+                for (int t = 0; t < 2; ++t) aux[i][t] = aux_load(i, t);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (HAS_AUX && i + 2 < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) aux[(i + 2) % 3][t] = aux_load(i + 2, t);
+            }
+            if (DIRECT) {
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq) {
+                    float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
+                                  acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
+                    if (HAS_BIAS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[2 * e] += __uint_as_float(biasp[jq][e] << 16);
+                            o[2 * e + 1] += __uint_as_float(biasp[jq][e] & 0xffff0000u);
+                        }
+                    }
+                    if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
+                    }
+                    *reinterpret_cast<u32x4*>(priv + frow_e * 128 + (((jq * 4 + fq_e) ^ ((frow_e >> 1) & 7)) << 4)) =
+                        u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                u32x4 v2[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = t * 8 + rr;
+                    v2[t] = *reinterpret_cast<const u32x4*>(priv + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int m = row_of(i, t);
+                    if (nok && m < p.M) *reinterpret_cast<u32x4*>((bf16_t*)p.C + dst_off(m)) = v2[t];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(priv + frow_e * 256 +
+                                              ((((j >> 1) * 8 + fq_e * 2 + (j & 1)) ^ (frow_e & 15)) << 4)) = acc[i][j];
+                // lanes exchange data through LDS inside one wave: the hardware runs a wave's DS instructions in order, the
+                // fences keep the COMPILER from moving a lane's accesses across the hand-over (no instruction is emitted)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f32x4 a2[2], b2[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = t * 8 + rr;
+                    a2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2) ^ (row & 15)) << 4));
+                    b2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2 + 1) ^ (row & 15)) << 4));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int m = row_of(i, t);
+                    const f32x4 a = a2[t], b = b2[t];
+                    if (nok && m < p.M) {
+                        float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                         if (HAS_BIAS) {
 #pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += bias8[e];
+                        }
+                        if (HAS_AUX) {
+                            const u32x4 w = aux[i % 3][t];
+#pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                o[2 * e] += __uint_as_float(biasp[jq][e] << 16);
-                                o[2 * e + 1] += __uint_as_float(biasp[jq][e] & 0xffff0000u);
+                                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                                if (EPI == GAR_EPI_BIAS_SCALE_RES) {
+                                    o[2 * e] = lo + gam8[2 * e] * o[2 * e];
+                                    o[2 * e + 1] = hi + gam8[2 * e + 1] * o[2 * e + 1];
+                                } else {
+                                    o[2 * e] += lo;
+                                    o[2 * e + 1] += hi;
+                                }
                             }
                         }
-                        if (EPI == GAR_EPI_BIAS_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
-                        }
-                        const int c16 = wn * 8 + jq * 4 + fq_e;
-                        *reinterpret_cast<u32x4*>(rp + ((c16 ^ (frow_e & 15)) << 4)) =
-                            u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                        st8((bf16_t*)p.C + dst_off(m), o);
                     }
                 }
             }
-        };
-        const int n = n0 + cg * 8;
-        const bool nok = n < p.N;
-        write_half(0);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            u32x4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = k * 16 + r0;
-                v[k] = *reinterpret_cast<const u32x4*>(E + row * 512 + ((cg ^ (row & 15)) << 4));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (c == 0) write_half(1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ml = c * 128 + k * 16 + r0;
-                if (nok && m0 + ml < p.M) {
-                    const int64_t off = p.tokens_out == -12346 ? (int64_t)ml * p.ldc + (n - n0)      // DEBUG: L2-resident stores
-                                                                : (int64_t)(m0 + ml) * p.ldc + n;
-                    *reinterpret_cast<u32x4*>((bf16_t*)p.C + off) = v[k];
-                }
-            }
-            if (c == 0) __builtin_amdgcn_s_barrier();
+            if (i == 0 && wm == 0) __builtin_amdgcn_s_barrier();      // un-stagger: row 1 has finished its last MFMAs by now
         }
     };
 
@@ -596,11 +674,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const unsigned tl_e0 = (unsigned)__builtin_amdgcn_s_memtime();
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
-        if (wm == 0) __builtin_amdgcn_s_barrier();
-        constexpr bool BF16_STAGE = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
-        if (PERM && LDS_EPI && BF16_STAGE && p.tokens_out != -12345) epilogue_lds_bf16(smem + (sidx ^ 1) * PSTAGE);
-        else if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
-        else epilogue();
+        constexpr bool WAVE_EPI = EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_SWIGLU;
+        if (PERM && LDS_EPI && WAVE_EPI && p.tokens_out != -12345) {
+            epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
+        } else {
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+            if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+            else epilogue();
+        }
 #if PP_TIMELINE == 4
         tl_sum[13] += (unsigned)__builtin_amdgcn_s_memtime() - tl_e0;          // un-stagger + epilogue
 #endif

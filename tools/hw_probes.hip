@@ -200,7 +200,7 @@ static void run_store(const char* name, int cus, int blocks, char* buf, size_t s
 
 // The GEMM epilogue's store pattern in isolation: persistent blocks walk 256x256 bf16 tiles of a row-major M x N matrix
 // in the kernel's tile order (8 m-tiles x all n-tiles per group, XCD-contiguous), each wave instruction writes 2 rows x
-// 512 B. ORDER 0: the kernel's order; 1: n-fastest inside a group.
+// 512 B. ORDER 0: the kernel's order; 1: n-fastest inside a group; 2: kernel order, per-wave 128 x 64 strips (8 rows x 128 B).
 template <int ORDER>
 __global__ __launch_bounds__(512) void tile_store_loop(char* dst, int M, int N, int reps) {
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -213,8 +213,20 @@ __global__ __launch_bounds__(512) void tile_store_loop(char* dst, int M, int N, 
             const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
             const int gsz = 8 * tiles_n, g = wg / gsz, first_m = g * 8;
             const int gm = min(tiles_m - first_m, 8), in = wg - g * gsz;
-            const int tm = ORDER == 0 ? first_m + in % gm : first_m + in / tiles_n;
-            const int tn = ORDER == 0 ? in / gm : in % tiles_n;
+            const int tm = ORDER != 1 ? first_m + in % gm : first_m + in / tiles_n;
+            const int tn = ORDER != 1 ? in / gm : in % tiles_n;
+            if (ORDER == 2) {        // per-wave 128 x 64 strips: one instruction = 8 rows x 128 B
+                const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+                for (int i = 0; i < 8; ++i)
+                    for (int t = 0; t < 2; ++t) {
+                        const int m = tm * 256 + wm * 128 + i * 16 + t * 8 + (lane >> 3);
+                        if (m < M) {
+                            char* ptr = dst + ((size_t)m * N + tn * 256 + wn * 64 + (lane & 7) * 8) * 2;
+                            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(val) : "memory");
+                        }
+                    }
+                continue;
+            }
             for (int c = 0; c < 4; ++c)
                 for (int k = 0; k < 4; ++k) {
                     const int m = tm * 256 + c * 64 + k * 16 + r0;
@@ -299,6 +311,7 @@ int main() {
         for (int N : {1024, 3072, 4096, 2048}) {
             run_tile_store<0>(cus, big, 139400, N);
             run_tile_store<1>(cus, big, 139400, N);
+            run_tile_store<2>(cus, big, 139400, N);
         }
         hipFree(big);
     }
