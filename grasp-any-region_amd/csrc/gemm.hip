@@ -343,7 +343,7 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
                            (e == GAR_EPI_BIAS && dtype == GAR_BF16) || dtype == GAR_F32),
                       "gar_gemm: fused RMSNorm prologue is built for the decode path only (M <= 64 bf16 / 16 f32)");
     if (e == GAR_EPI_QKV_ROPE)
-        GAR_CHECK_ARG(p.bias && p.qkv_q && p.qkv_k && p.qkv_sin && p.qkv_cos && p.qkv_heads > 0 && p.qkv_head_dim % 8 == 0 &&
+        GAR_CHECK_ARG(p.bias && p.qkv_q && p.qkv_k && p.qkv_sin && p.qkv_heads > 0 && p.qkv_head_dim % 8 == 0 &&
                           p.N == 3 * p.qkv_heads * p.qkv_head_dim && p.qkv_tokens > 0 && p.M % p.qkv_tokens == 0 &&
                           p.qkv_tokens_pad >= p.qkv_tokens && p.qkv_prefix >= 0 && p.qkv_prefix <= p.qkv_tokens,
                       "gar_gemm: QKV_ROPE args");

@@ -18,13 +18,17 @@
 //     instruction refetch) sits in the short phase 3, and the next K tile's address arithmetic is issued between the MFMAs
 //     of phase 3 (sched_group_barrier) — phase 0, 8 reads right behind the barrier that releases the stage, is the longest.
 //   epilogue: the W rows of an n-tile pair are fed in a permuted order so that a lane ends up with EIGHT consecutive
-//     output columns; the fp32 accumulators go through the just-consumed LDS stage in four 64-row chunks and are read
-//     back row-wise, so bias / LayerScale / residual loads and the stores are 16-byte vectors covering 512
-//     contiguous bytes per row (SwiGLU and the PERM=0 variant store straight from the fragments).
+//     output columns; every wave turns its own 128 x 64 strip into rows through a private 4-KiB piece of the
+//     just-consumed LDS stage, 16 rows at a time, without workgroup barriers (epilogue_wave: bf16-staged when the output
+//     is a function of accumulator and column, fp32-staged with row-side bias / LayerScale / residual / pos-embed / RoPE
+//     otherwise); stores are 16-byte vectors, 8 rows x 128 contiguous bytes per instruction. QKV_ROPE with full sin / cos
+//     tables keeps the older workgroup-level path (epilogue_lds: four 64-row fp32 chunks, 2 rows x 512 B per instruction);
+//     SwiGLU and the PERM=0 variant store straight from the fragments.
 //   Measured (tools/gemm_timeline.py with -DPP_TIMELINE=n builds, tools/bench_gemm.py): main loop
 //     1.45-1.59 PFLOP/s at a shader clock that the power limit holds at 1.4-1.65 GHz under this load (s_memtime ticks
-//     per wall second), i.e. ~0.9 of the matrix pipes' rate at that clock; the epilogue costs ~21k clocks per 256 x 256
-//     tile whatever the stores hit (HBM or one L2-resident tile).
+//     per wall second), i.e. ~0.9 of the matrix pipes' rate at that clock; the workgroup-level epilogue cost ~21k clocks per
+//     256 x 256 tile whatever the stores hit (HBM or one L2-resident tile), ~15k with hardware bf16 rounding; the per-wave
+//     epilogue is worth another 2-11 % per GEMM on top.
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
@@ -401,8 +405,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     // others are staged in fp32 and finished on the row side, with the row-dependent loads (residual / pos-embed)
     // issued two 16-row steps ahead: vmcnt retires in order, so a load issued behind a store waits for that store's ack.
     auto epilogue_wave = [&](char* E) {
+        constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;       // compact sin/cos table only (qkv_cos == NULL)
         constexpr bool DIRECT = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
-        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES;
+        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES || QKV;
         constexpr bool HAS_AUX = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES || EPI == GAR_EPI_PATCH_POS;
         int lane_e = lane, frow_e = frow, fq_e = fq;
         asm volatile("" : "+v"(lane_e), "+v"(frow_e), "+v"(fq_e));             // see epilogue_lds
@@ -440,6 +445,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             }
             return *reinterpret_cast<const u32x4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + nc);
         };
+        // QKV_ROPE: this lane's 8 columns are dims qd..qd+7 of head qh of q (part 0), k (1) or v (2); the rotation of row
+        // (token) tok needs the four (sin, cos) pairs of those dims: two 16-byte loads, issued one 16-row step ahead
+        const int Da = QKV ? p.qkv_heads * p.qkv_head_dim : 1;
+        const int part = QKV ? n / Da : 0;
+        const int nn = QKV ? n - part * Da : 0;
+        const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
+        auto sc_load = [&](int i, int t, int half) -> u32x4 {
+            const int m = min(row_of(i, t), p.M - 1);
+            const int tok = m - (m / p.qkv_tokens) * p.qkv_tokens;
+            const int rt = max(tok - p.qkv_prefix, 0);
+            return *reinterpret_cast<const u32x4*>(p.qkv_sin + ((int64_t)rt * p.qkv_head_dim + (nok && part < 2 ? qd : 0)) + half * 4);
+        };
+        u32x4 sc[2][2][2];
+        if (QKV) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) sc[0][t][hf] = sc_load(0, t, hf);
+        }
         u32x4 aux[3][2];
         if (HAS_AUX) {
 #pragma unroll
@@ -452,6 +476,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             if (HAS_AUX && i + 2 < 8) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) aux[(i + 2) % 3][t] = aux_load(i + 2, t);
+            }
+            if (QKV && i + 1 < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) sc[(i + 1) & 1][t][hf] = sc_load(i + 1, t, hf);
             }
             if (DIRECT) {
 #pragma unroll
@@ -533,7 +563,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                 }
                             }
                         }
-                        st8((bf16_t*)p.C + dst_off(m), o);
+                        if (QKV) {
+                            const int tile = m / p.qkv_tokens, tok = m - tile * p.qkv_tokens;
+                            if (part < 2) {
+                                if (tok >= p.qkv_prefix) {      // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const u32x4 w = sc[i & 1][t][e >> 1];
+                                        const float sn = __uint_as_float(w[(e & 1) * 2]), cs = __uint_as_float(w[(e & 1) * 2 + 1]);
+                                        const float x0 = o[2 * e], x1 = o[2 * e + 1];
+                                        o[2 * e] = x0 * cs + (-x1) * sn;
+                                        o[2 * e + 1] = x1 * cs + x0 * sn;
+                                    }
+                                }
+                                if (part == 0) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) o[e] *= p.qkv_q_scale;
+                                }
+                                st8((bf16_t*)(part == 0 ? p.qkv_q : p.qkv_k) +
+                                        (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
+                            } else {
+                                st8((bf16_t*)p.C + (int64_t)m * p.ldc + nn, o);
+                            }
+                        } else {
+                            st8((bf16_t*)p.C + dst_off(m), o);
+                        }
                     }
                 }
             }
@@ -674,8 +728,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const unsigned tl_e0 = (unsigned)__builtin_amdgcn_s_memtime();
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
-        constexpr bool WAVE_EPI = EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_SWIGLU;
-        if (PERM && LDS_EPI && WAVE_EPI && p.tokens_out != -12345) {
+        constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
+        if (PERM && LDS_EPI && WAVE_EPI && p.tokens_out != -12345 && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
         } else {
             if (wm == 0) __builtin_amdgcn_s_barrier();
