@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -119,6 +121,25 @@ def vit_qkv_post(qkv, sin, cos, Q, K, Vt, T, N, npt, H, hd, Npad, q_scale):
                                  H, hd, Npad, q_scale, stream()), "gar_vit_qkv_post")
 
 
+_SINCOS_CACHE = {}
+
+
+def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
+    """timm's RotaryEmbeddingCat repeats every angle for both elements of a rotated pair (repeat_interleave(2),
+    SURVEY.md A.1); when the tables have that form return the compact (sin, cos)-pair table the library's fast QKV_ROPE
+    epilogue reads (include/gar_hip.h: qkv_cos == NULL), else None. Cached per table pair; GAR_QKV_COMPACT=0 disables."""
+    if os.environ.get("GAR_QKV_COMPACT", "1") == "0":
+        return None
+    key = (sin.data_ptr(), cos.data_ptr(), tuple(sin.shape))
+    hit = _SINCOS_CACHE.get(key)
+    if hit is None:
+        ok = (sin.dtype == torch.float32 and cos.dtype == torch.float32 and sin.shape[-1] % 8 == 0 and
+              bool(torch.equal(sin[:, 0::2], sin[:, 1::2])) and bool(torch.equal(cos[:, 0::2], cos[:, 1::2])))
+        hit = (torch.stack([sin[:, 0::2], cos[:, 0::2]], dim=-1).contiguous() if ok else False, sin, cos)   # keeps the key's tensors alive
+        _SINCOS_CACHE[key] = hit
+    return hit[0] if hit[0] is not False else None
+
+
 def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale) -> bool:
     """qkv GEMM with the front half of timm AttentionRope fused (GAR_EPI_QKV_ROPE): q / k are rotated, scaled and written
     straight into Q / K [tiles, heads, tokens_pad, hd]; v goes row-major to ``v_out`` [M, heads*hd]. Returns False when the
@@ -132,7 +153,11 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     p.M, p.N, p.K = M, N, Kd
     p.epilogue = hip.EPI_QKV_ROPE
     p.bias = ptr(bias)
-    p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sin), ptr(cos)
+    sc = _compact_sincos(sin, cos)
+    if sc is not None:         # (sin, cos) pairs [tokens, hd/2, 2]: half the table bytes, the barrier-free per-wave epilogue
+        p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sc), None
+    else:
+        p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sin), ptr(cos)
     p.qkv_heads, p.qkv_head_dim, p.qkv_tokens, p.qkv_tokens_pad, p.qkv_prefix = heads, hd, tokens, tokens_pad, prefix
     p.qkv_q_scale = q_scale
     prof = KERNEL_TIMERS

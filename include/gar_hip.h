@@ -76,7 +76,9 @@ typedef struct gar_gemm_params {
                                        /* HF LlamaRMSNorm in front of q/k/v, gate/up and lm_head fused into the GEMM */
     /* GAR_EPI_QKV_ROPE only */
     void* qkv_q; void* qkv_k;          /* [tiles, heads, qkv_tokens_pad, head_dim]                                   */
-    const float* qkv_sin; const float* qkv_cos;   /* [qkv_tokens - qkv_prefix, head_dim]                             */
+    const float* qkv_sin; const float* qkv_cos;   /* [qkv_tokens - qkv_prefix, head_dim]; or qkv_cos == NULL and qkv_sin =   */
+                                                  /* compact (sin, cos) pairs [qkv_tokens - qkv_prefix, head_dim/2][2] when  */
+                                                  /* the tables repeat each value for both elements of a rotated pair (timm) */
     int32_t qkv_heads, qkv_head_dim, qkv_tokens, qkv_tokens_pad, qkv_prefix;
     float qkv_q_scale;
 } gar_gemm_params;

@@ -528,11 +528,14 @@ def test_abi_errors_are_reported_not_thrown(dev):
 
 
 @pytest.mark.parametrize("npt,hd,H", [(1, 64, 16), (0, 128, 8)])
-def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H):
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact, monkeypatch):
     """GAR_EPI_QKV_ROPE (q / k rotated, scaled and laid out by the qkv GEMM's epilogue + gar_vit_v_transpose) against the
     two-kernel path (GAR_EPI_BIAS GEMM -> gar_vit_qkv_post) and against an fp64 statement; the fused path rounds to
     bf16 once instead of twice, so the comparison is within bf16 rounding, not bitwise. Pad rows stay zero."""
     from gar_amd import hip, ops
+    # "1": compact (sin, cos)-pair table + barrier-free per-wave epilogue; "0": full tables + workgroup-level epilogue
+    monkeypatch.setenv("GAR_QKV_COMPACT", compact)
     dt = torch.bfloat16
     T, n = 4, 1024
     N = n + npt
