@@ -94,6 +94,22 @@ def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
         close(o2, F.silu(acc[:, :Fd]) * acc[:, Fd:], dt)
 
 
+def test_gemm_bf16_pingpong_patch_pos_epilogue(dev):
+    """GAR_EPI_PATCH_POS at a size that takes the ping-pong kernel (row m -> token 1 + m % n of tile m / n of a
+    [tiles, n + 1, N] output, + pos-embed row): element-wise against fp64; the cls slots stay untouched."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    T, n, N, K = 16, 1024, 1024, 128
+    a, w = q(rnd(T * n, K, seed=90), dt), q(rnd(N, K, seed=91, scale=K ** -0.5), dt)
+    pos = q(rnd(n + 1, N, seed=92, scale=0.2), dt)
+    x = torch.full((T, n + 1, N), 3.0, dtype=dt, device=dev)
+    ops.gemm(a.to(dev, dt), w.to(dev, dt), x.view(T * (n + 1), N), hip.EPI_PATCH_POS, pos=pos.to(dev, dt), tokens_in=n,
+             tokens_out=n + 1, token_offset=1)
+    ref = (a.double() @ w.double().T).view(T, n, N) + pos[1:].double()
+    close(x[:, 1:], ref, dt)
+    assert float((x[:, 0].float() - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [4, 200])
 def test_gemm_epilogues(dev, dt, M):
