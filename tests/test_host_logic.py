@@ -197,6 +197,42 @@ def test_compact_sincos_table_for_the_fused_rope_epilogue(monkeypatch):
     assert ops._compact_sincos(sin, cos) is None
 
 
+def test_processor_with_a_real_hf_tokenizer_directory(tmp_path):
+    """GARProcessor.from_pretrained on a directory holding a real `tokenizers` fast tokenizer (byte-level BPE without
+    merges, the Llama-3 / PLM special tokens at their released ids — built here, there is no hub access): the HF adapter
+    path gives the same sample as the stub tokenizer: same length, same special-token positions and ids (image-token
+    expansion, crop tokens, chat template), same text, identical pixel / mask tensors and boxes."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from gar_amd.processing import LLAMA3_SPECIALS
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    vocab = {ch: i for i, ch in enumerate(sorted(pre_tokenizers.ByteLevel.alphabet()))}
+    inv = {v: k for k, v in LLAMA3_SPECIALS.items()}
+    for i in range(256, max(LLAMA3_SPECIALS.values()) + 1):
+        vocab[inv.get(i, f"<|filler_{i}|>")] = i
+    tk = Tokenizer(models.BPE(vocab=vocab, merges=[]))
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    tk.add_special_tokens(list(LLAMA3_SPECIALS.keys()))
+    PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="<|eot_id|>", pad_token="<|end_of_text|>",
+                            bos_token="<|begin_of_text|>").save_pretrained(str(tmp_path))
+    cfg = GARConfig.gar_1b()
+    ph = GARProcessor.from_pretrained(str(tmp_path), cfg, max_num_tiles=4)
+    ps = GARProcessor.from_config(cfg, max_num_tiles=4)
+    assert type(ph.tokenizer).__name__ == "_HFTokenizerAdapter"
+    assert (ph.tokenizer.image_token_id, ph.tokenizer.eos_token_id) == (128002, 128009)
+    img, m = synthetic_image(1, 200, 160), synthetic_mask(1, 200, 160)
+    a = SingleRegionCaptionDataset(img, m, ph, data_dtype=torch.float32, device="cpu")[0]
+    b = SingleRegionCaptionDataset(img, m, ps, data_dtype=torch.float32, device="cpu")[0]
+    ia, ib = a["input_ids"][0], b["input_ids"][0]
+    assert ia.shape == ib.shape and int((ia == 128002).sum()) == int((ib == 128002).sum()) > 0
+    sa, sb = ia >= 128000, ib >= 128000
+    assert torch.equal(sa, sb) and torch.equal(ia[sa], ib[sb])
+    assert ph.tokenizer.decode(ia[~sa].tolist()) == ps.tokenizer.decode(ib[~sb].tolist())
+    assert torch.equal(a["pixel_values"], b["pixel_values"]) and torch.equal(a["global_mask_values"], b["global_mask_values"])
+    assert a["bboxes"] == b["bboxes"]
+
+
 def test_resampling_tables_for_gpu_preprocessing():
     """tap tables used by the device preprocessing: weights reproduce torch's antialiased bicubic exactly (a resize
     done with the tables in numpy, sequential fma order, equals F.interpolate), NEAREST indices = floor(i * in/out)."""
