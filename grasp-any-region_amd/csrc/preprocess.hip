@@ -8,7 +8,9 @@
 //       kernel's: t = src[0]*w[0]; t = fma(src[j], w[j], t) — results are bit-identical to the fp32 path of
 //       torch's upsample_bicubic2d_aa, then round-half-even + clamp to [0,255] as torchvision does for uint8 images.
 //   nearest (visual-prompt id matrix): index tables from the host.
-//   epilogue of both: ((v / 255) - mean) / std in fp32, cast, scatter into tile (yo / ts) * ncw + (xo / ts).
+//   epilogue of both: (v - 255 mean) / (255 std) in fp32 — HF's fused rescale_and_normalize (BaseImageProcessorFast:
+//       mean and std are multiplied by 1 / rescale_factor, then ONE subtract and ONE divide; (v / 255 - mean) / std
+//       differs from it by one ulp for some uint8 values) —, cast, scatter into tile (yo / ts) * ncw + (xo / ts).
 // HBM-bound, tiny next to the vision tower: a 1024^2 region is ~40 MB of tile writes.
 #include "common.h"
 
@@ -45,7 +47,7 @@ template <typename T>
 __device__ __forceinline__ void store_tile_pixel(T* out, float v, int c, int yo, int xo, int ts, int ncw, int tile0,
                                                  float mean, float stdv) {
     const int tile = tile0 + (yo / ts) * ncw + (xo / ts);
-    const float nv = (v / 255.0f - mean) / stdv;
+    const float nv = (v - mean * 255.0f) / (stdv * 255.0f);
     DT<T>::st(out + (((int64_t)tile * 3 + c) * ts + (yo % ts)) * ts + (xo % ts), nv);
 }
 

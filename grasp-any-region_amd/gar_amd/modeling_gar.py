@@ -65,6 +65,18 @@ def _llama_inv_freq(t) -> torch.Tensor:
     return inv
 
 
+def _on_model_device(fn):
+    """Run a public entry point with the model's device current: the C ABI launches on the current HIP device and
+    ``hip.stream()`` hands it torch's current stream of THAT device, so a model on cuda:1 must not enqueue on device 0."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class GARModel:
     def __init__(self, config: GARConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
                  device: str = "cuda:0"):
@@ -75,9 +87,11 @@ class GARModel:
         self.prompt_numbers = config.prompt_numbers
         self.crop_tokens_ids = list(config.crop_tokens_ids)
         check_weights(config, weights)
-        self._prepare_weights(weights)
+        with torch.cuda.device(self.device):
+            self._prepare_weights(weights)
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
+        self._llm_lru: List[tuple] = []
         self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
         # regions per vision-tower / prefill pass (decode serves all B at once)
         self.prefill_chunk = int(os.environ.get("GAR_PREFILL_CHUNK", "16"))
@@ -115,6 +129,7 @@ class GARModel:
             ts.extend(ly.values())
         return ts
 
+    @_on_model_device
     def broadcast_weights(self, src: int = 0):
         """RCCL broadcast of every prepared weight tensor from rank ``src`` (one-off, bucketed)."""
         from .dp import broadcast_tensors
@@ -209,15 +224,40 @@ class GARModel:
             self._rope_cache[max_pos] = (fr.cos().contiguous().to(self.device), fr.sin().contiguous().to(self.device))
         return self._rope_cache[max_pos]
 
+    # Workspaces. Families whose shapes follow the request (tiles of a chunk, prompt length) are CAPACITY based: one flat
+    # zero-filled allocation per (family, name) that only grows (x1.25) and is sliced into views, so an evaluation loop
+    # with a different prompt length / tile count per item (gar_amd/bench_loops.py) does not allocate per shape.
+    # Buffers a captured decode graph points at ("llm", "decode", "head") are keyed by their exact shape and never move;
+    # the KV-cache states are kept in an LRU of MAX_LLM_STATES entries (their graphs go with them).
+    _CAPACITY_FAMILIES = ("vit", "emb", "prefill")
+    MAX_LLM_STATES = 2
+
     def _buf(self, key: tuple, name: str, shape, dtype=None, zero=False):
+        dtype = dtype or self.dtype
+        if key[0] in self._CAPACITY_FAMILIES:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            fam = self._ws.setdefault((key[0],), {})
+            flat = fam.get(name)
+            if flat is None or flat.dtype != dtype or flat.numel() < n:
+                cap = n if flat is None or flat.dtype != dtype else max(n, int(flat.numel() * 1.25))
+                flat = torch.zeros(cap, dtype=dtype, device=self.device)      # zero: padding rows must stay finite
+                fam[name] = flat
+            return flat[:n].view(*shape)
         d = self._ws.setdefault(key, {})
         t = d.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             d[name] = t
         return t
 
+    def workspace_bytes(self) -> int:
+        """device bytes held by the cached workspaces (tests / soak checks)."""
+        return sum(t.numel() * t.element_size() for d in self._ws.values() for t in d.values())
+
     # ---- vision tower + projector (A1-A6) -----------------------------------------------------------------------------
+    @_on_model_device
     def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None):
         """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l]."""
         cfg = self.config
@@ -287,6 +327,7 @@ class GARModel:
         return feats
 
     # ---- inputs_embeds: embedding + placeholder scatter + RoI replay (A7-A11) -----------------------------------------
+    @_on_model_device
     def build_inputs_embeds(self, input_ids, feats, bboxes, aspect_ratios, tiles_per_sample: int, validate=True,
                             video_frame_tokens: Optional[Sequence[int]] = None):
         cfg = self.config
@@ -357,6 +398,14 @@ class GARModel:
     def _llm_state(self, B: int, Smax: int):
         t = self.config.mllm_config.text_config
         key = ("llm", B, Smax)
+        if key in self._llm_lru:
+            self._llm_lru.remove(key)
+        self._llm_lru.append(key)
+        while len(self._llm_lru) > self.MAX_LLM_STATES:
+            old = self._llm_lru.pop(0)
+            self._ws.pop(old, None)
+            for gk in [g for g in self._graphs if g[0] == old]:
+                del self._graphs[gk]
         L, Hkv, hd = t.num_hidden_layers, t.num_key_value_heads, t.head_dim
         st = dict(
             Kc=self._buf(key, "Kc", (L, B, Hkv, Smax, hd), zero=True),
@@ -450,17 +499,23 @@ class GARModel:
         return logits
 
     # ---- generate -------------------------------------------------------------------------------------------------
+    @_on_model_device
     @torch.no_grad()
     def generate(self, pixel_values=None, global_mask_values=None, aspect_ratios=None, bboxes=None, input_ids=None,
                  attention_mask=None, generation_config=None, output_hidden_states=None, return_dict=None,
                  max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
                  return_logits: bool = False, sync_every: int = 16, feature_replay_video: bool = False,
-                 video_frame_tokens: Optional[Sequence[int]] = None, **generate_kwargs) -> GenerateOutput:
+                 video_frame_tokens: Optional[Sequence[int]] = None, forced_tokens: Optional[torch.Tensor] = None,
+                 **generate_kwargs) -> GenerateOutput:
         """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428).
 
         B = input_ids.shape[0] samples are processed together (the reference handles B=1 per call; its loop over
         ``batch_idx`` is kept). ``pixel_values`` / ``global_mask_values``: [B*(T+1), 3, H, W] (flattened tiles as the
-        reference's callers pass them) or [B, T+1, 3, H, W]."""
+        reference's callers pass them) or [B, T+1, 3, H, W].
+
+        ``forced_tokens`` [B, n] (tests): teacher forcing — ``sequences`` / ``logits`` still report what the model chose at
+        every step, but the token fed back as step j's input is ``forced_tokens[:, j]``, so two models (bf16 vs f32) can be
+        compared on identical contexts over a whole caption."""
         gc = generation_config
         if gc is not None:
             get = (lambda k, d=None: gc.get(k, d)) if isinstance(gc, dict) else (lambda k, d=None: getattr(gc, k, d))
@@ -477,9 +532,13 @@ class GARModel:
         B, S = input_ids.shape
         if validate and attention_mask is not None and not bool((attention_mask != 0).all()):
             raise hip.GarError("padded attention_mask is not supported (the reference's callers pass all ones)")
-        Smax = _round_up(S + max_new_tokens, 64)
+        # KV capacity in buckets of 256 positions: evaluation loops with a different prompt length per item reuse one
+        # cache, one token buffer ([B, Smax], sliced) and one captured decode graph per bucket
+        if forced_tokens is not None:
+            forced_tokens = forced_tokens.to(self.device, torch.int64)
+        Smax = _round_up(S + max_new_tokens, 256)
         skey, st = self._llm_state(B, Smax)
-        out_tokens = self._buf(skey, "out_tokens", (B, max_new_tokens), torch.int64, zero=True)
+        out_tokens = self._buf(skey, "out_tokens", (B, Smax), torch.int64, zero=True)[:, :max_new_tokens]
         st["counters"].zero_()
         V = cfg.mllm_config.text_config.vocab_size
         tiles = 0
@@ -509,6 +568,8 @@ class GARModel:
                 ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)
             last = self._prefill(embeds, st, Smax, b0)
             lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1])
+            if forced_tokens is not None:
+                st["cur"][b0:b1].copy_(forced_tokens[b0:b1, 0])
             if return_logits:
                 first_logits.append(lg[:, :V].float().clone())
         all_logits = []
@@ -516,22 +577,26 @@ class GARModel:
             all_logits.append(torch.cat(first_logits, 0))
         # counters after prefill: pos = S (position of the next token), kv_len = S+1 (incl. it), step = 1
         st["counters"].copy_(torch.tensor([S, S + 1, 1, 0], dtype=torch.int32), non_blocking=False)
-        eos = set()
+        eos, eos_first = set(), None
         if eos_token_id is not None:
-            eos = set(int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]))
+            eos_list = [int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
+            eos, eos_first = set(eos_list), (eos_list[0] if eos_list else None)
         graph = None
-        if use_graph and not return_logits and max_new_tokens > 1 and os.environ.get("GAR_NO_GRAPH") != "1":
-            graph = self._decode_graph(st, B, Smax, out_tokens, skey)
+        if use_graph and max_new_tokens > 1 and os.environ.get("GAR_NO_GRAPH") != "1":
+            graph, graph_logits = self._decode_graph(st, B, Smax, out_tokens, skey)
         n_done = 1
         finished_at = [None] * B
         while n_done < max_new_tokens:
             if graph is not None:
                 graph.replay()
+                lg = graph_logits            # the buffer the captured step writes: copied out stream-ordered below
             else:
                 lg = self._decode_step(st, B, Smax, out_tokens)
-                if return_logits:
-                    all_logits.append(lg[:, :cfg.mllm_config.text_config.vocab_size].float().clone())
+            if return_logits:
+                all_logits.append(lg[:, :V].float().clone())
             n_done += 1
+            if forced_tokens is not None and n_done - 1 < forced_tokens.shape[1]:
+                st["cur"].copy_(forced_tokens[:, n_done - 1])
             if eos and (n_done % sync_every == 0 or n_done == max_new_tokens):
                 if self._all_finished(out_tokens, n_done, eos, finished_at):
                     break
@@ -540,7 +605,7 @@ class GARModel:
             self._all_finished(out_tokens, n_done, eos, finished_at)
             host = seq.tolist()
             cut = max((f if f is not None else n_done) for f in finished_at)
-            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
+            pad = pad_token_id if pad_token_id is not None else eos_first      # HF: pad defaults to eos_token_id[0]
             for b in range(B):
                 if finished_at[b] is not None:
                     for j in range(finished_at[b], cut):
@@ -561,7 +626,9 @@ class GARModel:
         return all(f is not None for f in finished_at)
 
     def _decode_graph(self, st, B, Smax, out_tokens, skey):
-        gkey = (skey, out_tokens.data_ptr(), out_tokens.shape[1])
+        """(graph, logits buffer of the captured step). out_tokens is a [:, :n] slice of the state's [B, Smax] buffer:
+        pointer and row stride depend on the state only, so one graph serves every max_new_tokens of the bucket."""
+        gkey = (skey, out_tokens.data_ptr(), out_tokens.stride(0))
         g = self._graphs.get(gkey)
         if g is None:
             saved = st["counters"].clone()
@@ -576,8 +643,8 @@ class GARModel:
             st["cur"].copy_(saved_cur)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                self._decode_step(st, B, Smax, out_tokens)
+                logits = self._decode_step(st, B, Smax, out_tokens)
             st["counters"].copy_(saved)                      # capture does not execute; keep state explicit
             st["cur"].copy_(saved_cur)
-            self._graphs[gkey] = g
+            g = self._graphs[gkey] = (g, logits)
         return g

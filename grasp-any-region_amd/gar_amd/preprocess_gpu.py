@@ -105,11 +105,19 @@ class GpuImageProcessor:
         return torch.from_numpy(rgb).to(self.device, non_blocking=True)             # [H, W, 3] uint8
 
     def single_tile(self, image: Image.Image, resample: Optional[str] = None) -> torch.Tensor:
+        with torch.cuda.device(self.device):            # kernels go to the current HIP device / its current stream
+            return self._single_tile(image, resample)
+
+    def _single_tile(self, image, resample):
         out = torch.empty(1, 3, self.tile_size, self.tile_size, dtype=self.dtype, device=self.device)
         self._resize_into(self._upload(image), out, 1, 1, 0, resample or self.resample)
         return out
 
     def __call__(self, image: Image.Image, resample: Optional[str] = None):
+        with torch.cuda.device(self.device):
+            return self._call(image, resample)
+
+    def _call(self, image, resample):
         resample = resample or self.resample
         src = self._upload(image)
         h, w = src.shape[:2]

@@ -119,13 +119,22 @@ class GARImageProcessor:
         self.image_mean = 0.5
         self.image_std = 0.5
 
+    def rescale_and_normalize(self, x: torch.Tensor) -> torch.Tensor:
+        """HF ``BaseImageProcessorFast.rescale_and_normalize`` with do_rescale and do_normalize (what
+        image_processing_perception_lm_fast.py:350-358 calls): mean and std are multiplied by 1 / rescale_factor = 255 and
+        the image is normalised ONCE in fp32, (x - 127.5) / 127.5 — not (x / 255 - 0.5) / 0.5, which differs by one ulp
+        for some uint8 values."""
+        mean = torch.tensor(self.image_mean, dtype=torch.float32) * (1.0 / (1.0 / 255.0))
+        std = torch.tensor(self.image_std, dtype=torch.float32) * (1.0 / (1.0 / 255.0))
+        return (x.to(torch.float32) - mean) / std
+
     def single_tile(self, image: Image.Image, resample: Optional[str] = None) -> torch.Tensor:
         """One frame -> one normalised tile [1,3,ts,ts] (the ``max_num_tiles=1`` branch of ``resize``, :268-286)."""
         resample = resample or self.resample
         rgb = np.asarray(image.convert("RGB"), dtype=np.uint8)
         x = torch.from_numpy(rgb.copy()).permute(2, 0, 1).contiguous()
         t = _resize_u8(x, (self.tile_size, self.tile_size), resample).to(torch.float32)
-        return ((t / 255.0 - self.image_mean) / self.image_std).unsqueeze(0)
+        return self.rescale_and_normalize(t).unsqueeze(0)
 
     def __call__(self, image: Image.Image, resample: Optional[str] = None):
         resample = resample or self.resample
@@ -138,7 +147,7 @@ class GARImageProcessor:
         big = _resize_u8(x, (n_h * ts, n_w * ts), resample)
         tiles = split_tiles(big.unsqueeze(0), n_w, n_h)[0]                     # [n, 3, ts, ts]
         stacked = torch.cat([thumb.unsqueeze(0), tiles], dim=0).to(torch.float32)
-        pix = (stacked / 255.0 - self.image_mean) / self.image_std
+        pix = self.rescale_and_normalize(stacked)
         return pix.unsqueeze(0), [n_w, n_h]                                    # [1, T+1, 3, ts, ts]
 
 

@@ -107,7 +107,9 @@ def synthetic_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     if leaf == "pos_embed":
         return 0.2 * _draw(name, shape, seed)
     if name.endswith("embed_tokens.weight"):
-        return 0.05 * _draw(name, shape, seed)
+        # small enough that a tied head's self-logit |e_t|^2 / rms(h) stays below the spread of the other logits
+        # (0.03^2 * 2048 = 1.8 against a logit sigma of ~1.4 at GAR-1B width): no t -> t self-loop under greedy decode
+        return 0.03 * _draw(name, shape, seed)
     if name == "mllm.lm_head.weight":
         return _draw(name, shape, seed) / math.sqrt(shape[1])
     if name == "mask_patch_embedding.weight":
@@ -118,7 +120,21 @@ def synthetic_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
         fan_in = shape[1] * shape[2] * shape[3]
         return _draw(name, shape, seed) / math.sqrt(fan_in)
     if len(shape) == 2:                                    # Linear [out, in]
-        return _draw(name, shape, seed) / math.sqrt(shape[1])
+        w = _draw(name, shape, seed) / math.sqrt(shape[1])
+        if name == PJ + "linear_2.weight":
+            # zero row sums: E[gelu(z)] > 0 would otherwise give every image token the same offset vector, and the
+            # attention average over thousands of image tokens would feed that constant to every decode step
+            w = w - w.mean(dim=1, keepdim=True)
+        # Llama attention: 4x sharper scores, half-weight output. With unit-variance q/k the softmax over a few
+        # thousand image tokens is near-uniform, the attention output is the same vector at every decode step and
+        # greedy decoding collapses onto one token after 1-2 steps ("what's weak" 2): a wrong RoPE
+        # position or a stale KV row would then go unnoticed. Sharper scores make the output depend on the query
+        # token and its position, so the synthetic captions do not repeat (asserted in tests/test_host_logic.py).
+        if name.startswith(LM) and name.endswith("self_attn.q_proj.weight"):
+            w = 4.0 * w
+        elif name.startswith(LM) and name.endswith("self_attn.o_proj.weight"):
+            w = 0.5 * w
+        return w
     return 0.02 * _draw(name, shape, seed)
 
 
@@ -161,11 +177,38 @@ def normalize_checkpoint(cfg, weights: Dict[str, torch.Tensor]) -> Dict[str, tor
     * timm Eva attention stores the fused-qkv bias either as ``attn.qkv.bias`` or as ``attn.q_bias`` /
       ``attn.v_bias`` (+ an optional ``attn.k_bias`` buffer, zero when missing), and un-fused checkpoints hold
       ``attn.{q,k,v}_proj.{weight,bias}``: all are folded into ``attn.qkv.{weight,bias}``;
-    * tensors the path does not use (rotary buffers, heads, optimizer leftovers) are ignored.
+    * tensors the path does not use (rotary buffers, heads, optimizer leftovers) are ignored — but tensors or flags that
+      WOULD change the forward pass and that this path does not implement raise instead of yielding plausible wrong
+      captions: a post-transformer ``norm.{weight,bias}`` / ``use_post_transformer_norm`` (the reference applies
+      ``self.norm``, modeling_perception_lm.py:216; PE-lang checkpoints have Identity there), a non-zero
+      ``patch_embed.proj.bias``, ``attn.{q,k}_norm``, a ``ref_feat_shape`` different from the feature grid (RoPE rescale);
+    * an untied ``mllm.lm_head.weight`` that differs from ``embed_tokens`` wins over a config that says (or defaults
+      to) ``tie_word_embeddings``.
     Modifies ``cfg`` in place, returns a new dict; nothing is copied unless it has to be concatenated."""
     import re
     v = cfg.mllm_config.vision_config
     W = dict(weights)
+    unsupported = [k for k in W if k.startswith(VT) and (
+        k[len(VT):] in ("norm.weight", "norm.bias", "fc_norm.weight", "fc_norm.bias") or
+        ".attn.q_norm." in k or ".attn.k_norm." in k or ".attn.norm." in k)]
+    pb = W.get(VT + "patch_embed.proj.bias")
+    if pb is not None and bool((pb != 0).any()):
+        unsupported.append(VT + "patch_embed.proj.bias")
+    if unsupported:
+        raise ValueError(f"checkpoint holds vision-tower tensors that change the forward pass and are not implemented "
+                         f"here: {sorted(unsupported)[:6]}")
+    if v.model_args.get("use_post_transformer_norm"):
+        raise ValueError("vision model_args.use_post_transformer_norm=True is not implemented (PE-lang uses Identity)")
+    pw = W.get(VT + "patch_embed.proj.weight")
+    if pw is not None and v.img_size // int(pw.shape[-1]) != v.grid:
+        raise ValueError(f"vision ref_feat_shape {v.grid} != feature grid {v.img_size // int(pw.shape[-1])} of the "
+                         f"{int(pw.shape[-1])}-px patch embedding: RoPE rescale is not implemented")
+    head, emb = W.get("mllm.lm_head.weight"), W.get(LM + "embed_tokens.weight")
+    if head is not None and emb is not None:
+        t = cfg.mllm_config.text_config
+        same = head.shape == emb.shape and (head.data_ptr() == emb.data_ptr() or bool(torch.equal(head, emb)))
+        if t.tie_word_embeddings and not same:
+            t.tie_word_embeddings = False          # the checkpoint's own head, not a silent fallback to the embedding
     blocks = set()
     pat = re.compile(re.escape(VT) + r"blocks\.(\d+)\.")
     for k in W:

@@ -409,6 +409,39 @@ def test_roi_replay_bit_exact_vs_oracle(dev, dt, bbox):
     assert torch.equal(e2.float().cpu(), emb)
 
 
+def _kat_cases():
+    import parity_util as PU
+    return PU.roi_kat_cases()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("case", _kat_cases(), ids=lambda c: c[0])
+def test_roi_replay_hand_derived_known_answers(dev, dt, case):
+    """The replay kernel against the hand-derived roi_align known answers of tests/parity_util.py (aligned half-pixel
+    shift, the two sampling_ratio=2 sample positions at a non-integer bin size, the y <= 0 clamp, the last-cell branch,
+    out-of-range samples, a box straddling two tiles of the tile layout, the reference's double scaling) — the same
+    closed forms the numpy oracle and its C twin are held to on the CPU. The thumbnail tile is filled with 1e9 and must
+    never be read. The map cells the samples touch are exactly representable in bf16; bf16 outputs round once."""
+    import parity_util as PU
+    from gar_amd import ops
+    name, ncw, nch, chans, roi, ss, _ = case
+    fmap, exp = PU.kat_feature_map(case)
+    C, Cc, P, S = fmap.shape[0], 64, 16, 300
+    tiles = torch.zeros(1 + ncw * nch, P * P, Cc)
+    tiles[:, :, :C] = PU.tiles_from_map(fmap, ncw, nch)
+    tiles[0] = 1.0e9
+    emb = torch.full((S, Cc), -7.0)
+    spans = torch.tensor([[-1, -1], [20, 275], [-1, -1], [-1, -1], [-1, -1]], dtype=torch.int32, device=dev)
+    e = emb.to(dev, dt).clone()
+    ops.roi_replay(tiles.to(dev, dt), e, spans, 1, 1, ncw, nch, P, Cc, S, roi, ss, 2, True)
+    out = e.float().cpu()
+    assert float((out[:20] + 7.0).abs().max()) == 0 and float((out[276:] + 7.0).abs().max()) == 0
+    got = out[20:276, :C].double().T.reshape(C, P, P)
+    lim = 2e-5 if dt == torch.float32 else 4e-3 * max(1.0, float(exp.abs().max()))
+    assert float((got - exp).abs().max()) < lim, (name, float((got - exp).abs().max()))
+    assert float(out[20:276, C:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_roi_replay_batched_equals_per_token_launches(dev, dt):
     """one launch over (sample, crop token) jobs == the per-token kernel, bit for bit; ragged: sample 1 has two crop
