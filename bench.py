@@ -40,7 +40,11 @@ def parse():
                     help="regions per step per GPU (continuous batching of independent regions)")
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--max-num-tiles", type=int, default=16)
-    ap.add_argument("--model", default="gar_1b")
+    ap.add_argument("--workload", choices=["single", "multi_region", "video"], default="single",
+                    help="single: BASELINE.json configs[1] (1 mask / region, the headline metric); multi_region: configs[2] "
+                         "(4 masks per image, relationship prompt, demo/gar_relationship.py path); video: configs[4] "
+                         "shape on one GPU (8-frame 1024^2 clip, per-frame mask, GAR-8B video replay)")
+    ap.add_argument("--model", default=None, help="gar_1b | gar_8b (default: gar_8b for --workload video, else gar_1b)")
     ap.add_argument("--pool", type=int, default=2, help="distinct pre-staged synthetic samples per rank")
     ap.add_argument("--preprocess", choices=["resident", "device"], default="resident",
                     help="resident (default, the bench contract): model inputs already in HBM. device: every step also "
@@ -48,18 +52,37 @@ def parse():
                          "raw uint8 image, resize/tile/normalise kernels of preprocess.hip) inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.model is None:
+        a.model = "gar_8b" if a.workload == "video" else "gar_1b"
+    if a.workload == "video" and a.max_num_tiles == 16:
+        a.max_num_tiles = 8                      # GAR-8B's tile budget (configs/gar_8b.py:101); frames are one tile each
+    return a
 
 
-def build_batches(cfg, proc, rank, world, B, pool, device):
+DISTINCT_SAMPLES = 4      # host bicubic preprocessing is slow: this many distinct synthetic samples, tiled to fill a batch
+
+
+def build_sample(workload, proc, i):
+    """one synthetic sample of the workload on the CPU, bf16 (seeded by the global region index i)."""
+    from gar_amd.eval_dataset import MultiRegionDataset, SingleRegionCaptionDataset, VideoRegionCaptionDataset
+    from gar_amd.synthetic import RELATIONSHIP_QUESTION, synthetic_disjoint_masks, synthetic_image, synthetic_mask
+    if workload == "multi_region":       # 4 disjoint masks, prompt ids 0-3, fixed relationship question (SURVEY.md 8d)
+        return MultiRegionDataset(synthetic_image(i), synthetic_disjoint_masks(i, 4), RELATIONSHIP_QUESTION, proc,
+                                  data_dtype=torch.bfloat16, device="cpu")[0]
+    if workload == "video":              # 8 frames of 1024^2, one mask per frame, one tile + one crop token per frame
+        frames = [synthetic_image(8 * i + f) for f in range(8)]
+        masks = [synthetic_mask(8 * i + f) for f in range(8)]
+        return VideoRegionCaptionDataset(frames, masks, proc, data_dtype=torch.bfloat16, device="cpu")[0]
+    return SingleRegionCaptionDataset(synthetic_image(i), synthetic_mask(i), proc, data_dtype=torch.bfloat16,
+                                      device="cpu")[0]
+
+
+def build_batches(cfg, proc, rank, world, B, pool, device, workload="single"):
     """`pool` distinct batches of B samples each, already on the GPU in bf16 (seeded per global region index)."""
-    from gar_amd.eval_dataset import SingleRegionCaptionDataset
-    from gar_amd.synthetic import synthetic_image, synthetic_mask
     singles = []
-    for j in range(pool * B if pool * B <= 4 else 4):          # host bicubic preprocessing is slow: 4 distinct images
-        i = rank * 1000 + j
-        singles.append(SingleRegionCaptionDataset(synthetic_image(i), synthetic_mask(i), proc,
-                                                  data_dtype=torch.bfloat16, device="cpu")[0])
+    for j in range(pool * B if pool * B <= DISTINCT_SAMPLES else DISTINCT_SAMPLES):
+        singles.append(build_sample(workload, proc, rank * 1000 + j))
     batches = []
     for pidx in range(pool):
         sel = [singles[(pidx * B + k) % len(singles)] for k in range(B)]
@@ -69,6 +92,8 @@ def build_batches(cfg, proc, rank, world, B, pool, device):
             global_mask_values=torch.cat([s["global_mask_values"] for s in sel]).to(device),
             bboxes=[s["bboxes"][0] for s in sel],
             aspect_ratios=torch.cat([s["aspect_ratios"] for s in sel]).to(device)))
+        if workload == "video":
+            batches[-1].update(feature_replay_video=True, video_frame_tokens=sel[0]["video_frame_tokens"])
     return batches, singles[0]
 
 
@@ -111,6 +136,12 @@ def cpu_baseline(cfg, W, sample, new_tokens, threads):
     return {"value": 1.0 / total, "unit": "regions/s", "cores": cores, "kind": "port",
             "sample": f"1 region: {nt}/{T} ViT tiles x all layers (x{T / nt:.1f}), full embed+RoI replay, full prefill "
                       f"S={emb.shape[1]}, {nd}/{new_tokens} decode steps (x{new_tokens / nd:.0f}); fp32 torch-CPU oracle",
+            "extrapolated": True,
+            "extrapolation": {"vit+projector": T / nt, "assemble+replay": 1.0, "prefill": 1.0, "decode": new_tokens / nd},
+            "note": "EXTRAPOLATED from the bounded sample by the factors above. `cores` = torch intra-op threads (all "
+                    "hardware threads of the box, SMT included: oversubscribed for the one-row decode GEMVs); the decode "
+                    "leg is dominated by the oracle's own bookkeeping (torch.cat KV cache growth, repeat_interleave of "
+                    "K/V for GQA), not by the reference algorithm — a reported baseline, not a tuned CPU implementation",
             "seconds_per_region": total,
             "stage_seconds": {"vit+projector": t_vit, "assemble+replay": t_asm, "prefill": t_pre, "decode": t_dec}}
 
@@ -134,7 +165,9 @@ def main():
     else:
         model = GARModel.from_shapes(cfg, torch.bfloat16, device)
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
-    batches, one = build_batches(cfg, proc, rank, world, args.batch, args.pool, device)
+    if args.workload != "single" and args.preprocess == "device":
+        raise SystemExit("--preprocess device is wired for --workload single")
+    batches, one = build_batches(cfg, proc, rank, world, args.batch, args.pool, device, args.workload)
     B = args.batch
     S = batches[0]["input_ids"].shape[1]
     tiles = batches[0]["pixel_values"].shape[0] // B
@@ -223,27 +256,49 @@ def main():
                 "launches": cnt, "avg_launch_us": sec / cnt * 1e6, "flop_per_launch": fl / cnt,
                 "algorithmic_bytes_per_launch": nb / cnt, "time_share_of_step": sec / elapsed}
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
-        # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                k = json.load(open(pmc))["kernels"]["gemm_bf16_pp_kernel"]
-                roof["traffic"] = k["traffic_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-            except Exception:
-                pass
+        # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/ (newest round first)
+        for rnd in ("r2", "r1"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+            if args.workload == "single" and args.model == "gar_1b" and os.path.exists(pmc):
+                try:
+                    k = json.load(open(pmc))["kernels"]["gemm_bf16_pp_kernel"]
+                    roof["traffic"] = k["traffic_bytes_per_launch"]
+                    roof["traffic_source"] = f"profiles/{rnd}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    break
+                except Exception:
+                    pass
     value = world * args.steps * B / elapsed
     mname = {"gar_1b": "GAR-1B", "gar_8b": "GAR-8B"}.get(args.model, args.model)
-    cfg_idx = {"gar_1b": "configs[1]", "gar_8b": "configs[3] shape, one GPU"}.get(args.model, "parity config")
-    line = {"metric": f"regions/sec (1024^2 img, 1 mask, 64-tok caption) {mname}", "value": value, "unit": "regions/s",
+    if args.workload == "multi_region":
+        metric, unit = f"prompts/sec (1024^2 img, 4 masks, relationship prompt, 64-tok answer) {mname}", "prompts/s"
+        wl = f"{mname} bf16, synthetic 1024x1024 images, 4 masks/image multi-region relationship prompt " \
+             f"(gar_relationship.py path), {args.new_tokens}-token greedy answer (BASELINE.json configs[2])"
+    elif args.workload == "video":
+        metric, unit = f"clips/sec (8-frame 1024^2 clip, per-frame mask, 64-tok caption) {mname}", "clips/s"
+        wl = f"{mname} bf16 video replay, synthetic 8-frame 1024x1024 clips with a per-frame mask (VideoRefer-style), " \
+             f"{args.new_tokens}-token greedy caption (BASELINE.json configs[4] shape on {world} GPU)"
+    else:
+        cfg_idx = {"gar_1b": "configs[1]", "gar_8b": "configs[3] shape"}.get(args.model, "parity config")
+        metric, unit = f"regions/sec (1024^2 img, 1 mask, 64-tok caption) {mname}", "regions/s"
+        wl = f"{mname} bf16, synthetic 1024x1024 images, 1 mask/region, {args.new_tokens}-token greedy caption " \
+             f"(BASELINE.json {cfg_idx})"
+    ids0 = batches[0]["input_ids"][0]
+    n_crop_rows = int(sum(int((ids0 == t).sum()) for t in (batches[0].get("video_frame_tokens") or cfg.crop_tokens_ids)))
+    line = {"metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{mname} bf16, synthetic 1024x1024 images, 1 mask/region, 64-token greedy caption "
-                                   f"(BASELINE.json {cfg_idx})",
+            "config": {"workload": wl,
                        "regions_per_step_per_gpu": B, "tiles_per_region": tiles, "prefill_len": S,
+                       "replayed_rows_per_region": n_crop_rows,
                        "new_tokens": args.new_tokens, "max_num_tiles": args.max_num_tiles,
                        "inputs": "resident in HBM" if args.preprocess == "resident" else
                                  "built per step from host images (device preprocessing inside the timed region)",
+                       "distinct_samples": f"{min(DISTINCT_SAMPLES, args.pool * B)} distinct synthetic samples per rank, "
+                                           f"repeated to fill the {B}-region batch (host bicubic sample building is slow)",
+                       "validate": False,
+                       "validate_note": "generate(validate=False): the reference's image-token count / missing-bbox "
+                                        "checks (host syncs) are skipped inside the timed region",
+                       "eos": "disabled (exactly new_tokens tokens per region)",
                        "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},
             "roofline": roof}
@@ -252,21 +307,28 @@ def main():
         line["roofline_other"] = {"gemm_skinny_bf16(prefill head only; decode runs inside the hipGraph)":
                                   {"bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "launches": cnt}}
-    # HBM-bound "replay pass" (pool -> embed + scatter -> RoI replay; SURVEY.md section 8d: ~90 MB per region)
-    hb = [agg[k] for k in ("pool2x2", "embed_assemble", "roi_replay") if k in agg]
+    # HBM-bound RoI feature-replay pass (pool + embed/scatter + RoI replay), priced at SURVEY.md section 8d's ALGORITHMIC
+    # bytes: the projector's grid rows read once + the sequence written once + the RoI cells (~90 MB per region at GAR-1B /
+    # 1024^2). Since round 2 the pass IS that traffic: gar_pool_assemble pools on the way into the sequence and
+    # gar_roi_replay_inplace reads the pooled rows back from it (round 1 wrote and re-read the pooled features: 128.9 MB).
+    hb = [agg[k] for k in ("pool_assemble", "roi_replay") if k in agg]
     if hb:
         nb, sec = sum(a[1] for a in hb), sum(a[2] for a in hb)
-        line.setdefault("roofline_other", {})["pool2x2 + embed_assemble + roi_replay pass"] = {
+        line.setdefault("roofline_other", {})["RoI feature-replay pass (pool_assemble + roi_replay_inplace)"] = {
             "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_region": nb / (args.steps * B),
-            "launches": sum(a[3] for a in hb)}
+            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_region": nb / (args.steps * B),
+            "us_per_region": sec / (args.steps * B) * 1e6, "launches": sum(a[3] for a in hb)}
     if "roi_replay" in agg:
         fl, nb, sec, cnt = agg["roi_replay"]
-        line.setdefault("roofline_other", {})["roi_replay_batched_kernel alone (one launch per 16-region chunk)"] = {
+        line.setdefault("roofline_other", {})["roi_replay_inplace_kernel alone (one launch per 16-region chunk; ~1 MB per "
+                                              "crop token: launch / latency bound)"] = {
             "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": nb / cnt, "avg_launch_us": sec / cnt * 1e6,
             "launches": cnt}
-    if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
+    if not args.no_cpu_baseline and world == 1 and args.workload == "video":
+        line["cpu_baseline"] = {"value": None, "note": "the CPU oracle leg is wired for the image workloads (run "
+                                                       "--workload single for the headline line's baseline)"}
+    elif not args.no_cpu_baseline and world == 1:        # reported on rank 0 at N=1 only
         try:
             line["cpu_baseline"] = cpu_baseline(cfg, W, one, args.new_tokens, args.cpu_threads)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(1024) void placeholder_scan_kernel(const int64_t* _
                                                                 int64_t image_id, const int64_t* __restrict__ crop_ids,
                                                                 int n_crop, int32_t* __restrict__ slot,
                                                                 int32_t* __restrict__ counts,
-                                                                int32_t* __restrict__ spans) {
+                                                                int32_t* __restrict__ spans,
+                                                                int32_t* __restrict__ rank_pos, int rank_stride) {
     __shared__ int wave_tot[16];
     __shared__ int smin[8], smax[8];
     __shared__ int running;
@@ -41,6 +42,9 @@ __global__ __launch_bounds__(1024) void placeholder_scan_kernel(const int64_t* _
         for (int w = 0; w < wave; ++w) off += wave_tot[w];
         if (s < S) {
             slot[(int64_t)b * S + s] = flag ? off + prefix : -1;
+            // inverse map (rank of an image token -> its position): lets the replay read pooled features straight from
+            // the assembled sequence wherever the placeholders sit
+            if (rank_pos && flag && off + prefix < rank_stride) rank_pos[(int64_t)b * rank_stride + off + prefix] = s;
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if (v == cid[c]) { lmin[c] = min(lmin[c], s); lmax[c] = max(lmax[c], s); }
@@ -66,11 +70,12 @@ __global__ __launch_bounds__(1024) void placeholder_scan_kernel(const int64_t* _
 
 extern "C" int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int64_t image_token_id,
                                     const int64_t* crop_ids, int n_crop, int32_t* slot, int32_t* counts, int32_t* spans,
-                                    gar_stream_t stream) {
+                                    int32_t* rank_pos, int rank_stride, gar_stream_t stream) {
     GAR_CHECK_ARG(input_ids && slot && counts && spans && B > 0 && S > 0, "placeholder_scan: bad args");
+    GAR_CHECK_ARG(!rank_pos || rank_stride > 0, "placeholder_scan: rank_pos without rank_stride");
     GAR_CHECK_ARG(n_crop >= 0 && n_crop <= 8 && (n_crop == 0 || crop_ids), "placeholder_scan: n_crop must be <= 8");
     hipLaunchKernelGGL(placeholder_scan_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, input_ids, S,
-                       image_token_id, crop_ids, n_crop, slot, counts, spans);
+                       image_token_id, crop_ids, n_crop, slot, counts, spans, rank_pos, rank_stride);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }
@@ -115,6 +120,79 @@ extern "C" int gar_embed_assemble(int dtype, const int64_t* input_ids, const int
     else
         hipLaunchKernelGGL((embed_assemble_kernel<float>), grid, block, 0, s, input_ids, slot, (const float*)E,
                            (const float*)feats, (float*)out, S, C, n_feat_rows, vocab);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pool_assemble: PerceptionLMAdaptiveAvgPooling (2x2 mean, modeling_perception_lm.py:47-60) + nn.Embedding +
+// masked_scatter (modeling_gar.py:332,341-346) in ONE pass: an image-token row of the sequence is the 2x2 mean of four
+// projector-output rows (rounded once to the storage dtype, as the pool's output is), any other row is its embedding.
+// The pooled features are never written on their own: the RoI replay below reads them back from the sequence rows
+// (rank_pos). Algorithmic bytes per region: projector grid rows read once (T*g*g*C) + the sequence written once (S*C)
+// = SURVEY.md section 8d's ~90 MB at GAR-1B / 1024^2. One block per sequence row, 8 channels per thread.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_assemble_kernel(const int64_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ slot, const T* __restrict__ E,
+                                                            const T* __restrict__ proj, T* __restrict__ out, int S, int C,
+                                                            int64_t n_feat_rows, int64_t vocab, int g,
+                                                            int in_tile_tokens, int in_token_offset,
+                                                            int64_t proj_rows_per_sample) {
+    const int64_t r = blockIdx.x;                         // row over B*S
+    const int b = (int)(r / S);
+    const int32_t sl = slot[r];
+    T* dst = out + r * C;
+    if (sl >= 0) {
+        const int go = g >> 1;
+        const int64_t rk = min((int64_t)sl, n_feat_rows - 1);
+        const int t = (int)(rk / (go * go)), k = (int)(rk - (int64_t)t * go * go);
+        const int oy = k / go, ox = k - oy * go;
+        const T* base = proj + ((int64_t)b * proj_rows_per_sample + (int64_t)t * in_tile_tokens + in_token_offset) * C;
+        const T* p00 = base + (int64_t)((2 * oy) * g + 2 * ox) * C;
+        for (int i = threadIdx.x * 8; i < C; i += 256 * 8) {
+            float a[8], bb[8], c[8], d[8], o[8];
+            ld8(p00 + i, a);
+            ld8(p00 + C + i, bb);
+            ld8(p00 + (int64_t)g * C + i, c);
+            ld8(p00 + (int64_t)(g + 1) * C + i, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (((a[e] + bb[e]) + c[e]) + d[e]) * 0.25f;      // pool2x2_kernel's order
+            st8(dst + i, o);
+        }
+    } else {
+        int64_t id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const T* src = E + id * C;
+        for (int i = threadIdx.x * 8; i < C; i += 256 * 8) {
+            if (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+            else {
+                reinterpret_cast<float4*>(dst + i)[0] = reinterpret_cast<const float4*>(src + i)[0];
+                reinterpret_cast<float4*>(dst + i)[1] = reinterpret_cast<const float4*>(src + i)[1];
+            }
+        }
+    }
+}
+
+extern "C" int gar_pool_assemble(int dtype, const int64_t* input_ids, const int32_t* slot, const void* E,
+                                 const void* proj, void* out, int B, int S, int C, int tiles_per_sample, int g,
+                                 int in_tile_tokens, int in_token_offset, int64_t vocab, gar_stream_t stream) {
+    GAR_CHECK_ARG(input_ids && slot && E && proj && out && B > 0 && S > 0 && C % 8 == 0, "pool_assemble: bad args");
+    GAR_CHECK_ARG(tiles_per_sample > 0 && g > 0 && g % 2 == 0, "pool_assemble: bad grid");
+    if (in_tile_tokens <= 0) in_tile_tokens = g * g;
+    GAR_CHECK_ARG(in_token_offset >= 0 && in_token_offset + g * g <= in_tile_tokens, "pool_assemble: bad token window");
+    const int64_t n_feat_rows = (int64_t)tiles_per_sample * (g / 2) * (g / 2);
+    const int64_t proj_rows = (int64_t)tiles_per_sample * in_tile_tokens;
+    dim3 grid((unsigned)((int64_t)B * S)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((pool_assemble_kernel<bf16_t>), grid, block, 0, s, input_ids, slot, (const bf16_t*)E,
+                           (const bf16_t*)proj, (bf16_t*)out, S, C, n_feat_rows, vocab, g, in_tile_tokens,
+                           in_token_offset, proj_rows);
+    else
+        hipLaunchKernelGGL((pool_assemble_kernel<float>), grid, block, 0, s, input_ids, slot, (const float*)E,
+                           (const float*)proj, (float*)out, S, C, n_feat_rows, vocab, g, in_tile_tokens, in_token_offset,
+                           proj_rows);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }
@@ -184,10 +262,10 @@ template <> struct Raw8<float> {
 // likewise: the block loads each DISTINCT cell once (typically 2 x 2 instead of 16 — the bin is smaller than a
 // cell for every realistic mask) and then runs torchvision's arithmetic in its original order on the copies.
 template <typename T, int G>
-__device__ __forceinline__ void roi_replay_row(const T* __restrict__ feats, T* __restrict__ embeds, int head, int ph,
+__device__ __forceinline__ void roi_replay_row(const T* feats, T* embeds, int head, int ph,
                                                int pw, int c0, int cstride, int first_tile, int ncw, int nch, int P,
                                                int C, int S, float rx1, float ry1, float rx2, float ry2, float ss,
-                                               int aligned) {
+                                               int aligned, const int32_t* __restrict__ rank_pos = nullptr) {
     static_assert(G == 2, "sampling_ratio 2");
     const int row = head + ph * P + pw;
     if (row >= S) return;
@@ -210,7 +288,9 @@ __device__ __forceinline__ void roi_replay_row(const T* __restrict__ feats, T* _
     const int X[4] = {ax[0].lo, ax[0].hi, ax[1].lo, ax[1].hi};
     auto cell = [&](int y, int x) -> const T* {            // merged-map cell (y,x) in the tile-major layout
         const int tile = first_tile + (y / P) * ncw + (x / P);
-        return feats + ((int64_t)tile * P * P + (y % P) * P + (x % P)) * C;
+        const int64_t rank = (int64_t)tile * P * P + (y % P) * P + (x % P);
+        // in-place form: `feats` is the assembled sequence of this sample and the pooled token of rank r sits in row rank_pos[r]
+        return feats + (rank_pos ? (int64_t)rank_pos[rank] : rank) * C;
     };
     T* dst = embeds + (int64_t)row * C;
     for (int c = c0; c < C; c += cstride) {
@@ -296,6 +376,43 @@ __global__ __launch_bounds__(RB) void roi_replay_batched_kernel(const T* __restr
     roi_replay_row<T, G>(feats + (int64_t)j.sample * tiles_per_sample * P * P * C, embeds + (int64_t)j.sample * S * C,
                          head, blockIdx.x / P, blockIdx.x % P, threadIdx.x * 8, RB * 8, j.first_tile, j.ncw, j.nch, P, C,
                          S, j.x1, j.y1, j.x2, j.y2, j.spatial_scale, aligned);
+}
+
+// in-place form: the pooled features are the image-token rows of `embeds` itself (written by pool_assemble); rank_pos
+// [B, rank_stride] maps the rank of a pooled token (tile * P*P + token) to its sequence position. The crop-token rows it
+// writes are disjoint from the image-token rows it reads.
+template <typename T, int G>
+__global__ __launch_bounds__(RB) void roi_replay_inplace_kernel(T* __restrict__ embeds, const int32_t* __restrict__ spans,
+                                                                const int32_t* __restrict__ rank_pos, int rank_stride,
+                                                                const gar_roi_job* __restrict__ jobs, int n_crop, int P,
+                                                                int C, int S, int aligned) {
+    const gar_roi_job j = jobs[blockIdx.y];
+    const int head = spans[((int64_t)j.sample * n_crop + j.crop_index) * 2];
+    if (head < 0) return;
+    T* seq = embeds + (int64_t)j.sample * S * C;
+    roi_replay_row<T, G>(seq, seq, head, blockIdx.x / P, blockIdx.x % P, threadIdx.x * 8, RB * 8, j.first_tile, j.ncw,
+                         j.nch, P, C, S, j.x1, j.y1, j.x2, j.y2, j.spatial_scale, aligned,
+                         rank_pos + (int64_t)j.sample * rank_stride);
+}
+
+extern "C" int gar_roi_replay_inplace(int dtype, void* embeds, const int32_t* spans, const int32_t* rank_pos,
+                                      int rank_stride, const gar_roi_job* jobs, int n_jobs, int n_crop, int P, int C,
+                                      int S, int sampling_ratio, int aligned, gar_stream_t stream) {
+    GAR_CHECK_ARG(embeds && spans && jobs && rank_pos, "roi_replay_inplace: null pointer");
+    GAR_CHECK_ARG(n_jobs > 0 && n_jobs <= 65535 && n_crop > 0 && rank_stride > 0 && P > 0 && C % 8 == 0 && S > 0,
+                  "roi_replay_inplace: bad shape");
+    GAR_CHECK_ARG(sampling_ratio == 2, "roi_replay_inplace: sampling_ratio %d not built (the reference uses 2)",
+                  sampling_ratio);
+    dim3 grid(P * P, n_jobs), block(RB);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((roi_replay_inplace_kernel<bf16_t, 2>), grid, block, 0, s, (bf16_t*)embeds, spans, rank_pos,
+                           rank_stride, jobs, n_crop, P, C, S, aligned);
+    else
+        hipLaunchKernelGGL((roi_replay_inplace_kernel<float, 2>), grid, block, 0, s, (float*)embeds, spans, rank_pos,
+                           rank_stride, jobs, n_crop, P, C, S, aligned);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
 }
 
 extern "C" int gar_roi_replay(int dtype, const void* feats, void* embeds, const int32_t* spans, int crop_index,

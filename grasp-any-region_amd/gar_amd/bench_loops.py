@@ -253,3 +253,78 @@ def run_mdvp_bench(argv=None):
     json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
     print(f"Cache name: {args.cache_name}")
     return path
+
+
+def sample_frame_indices(n_frames: int, n_keep: int = 8):
+    """``n_keep`` indices spread uniformly over ``n_frames`` (first and last included), all of them when fewer."""
+    if n_frames <= n_keep:
+        return list(range(n_frames))
+    return [round(i * (n_frames - 1) / (n_keep - 1)) for i in range(n_keep)]
+
+
+def run_video_refer(argv=None):
+    """VideoRefer-style driver for the video replay path (A13, modeling_perception_lm.py:765-852). The reference ships
+    the model-side code of that path but no caller, so the annotation layout is this
+    repo's, modelled on VideoRefer-Bench's mask annotations:
+
+        [{"id": ..., "video": "<directory of frame images>" | "frames": ["f0.jpg", ...],
+          "annotation": [{"<frame index>": {"segmentation": <COCO RLE | polygons>}}, ...]   # one object, per-frame masks
+          | "masks": {"<frame index>": <RLE | polygons>},
+          "question": "..." (optional)}]
+
+    Up to 8 annotated frames per clip (uniformly sampled when there are more — the path has five crop tokens plus the
+    following reserved ids, 8 frames at most); each frame becomes ONE 448-px tile with its own mask and crop token
+    (``VideoRegionCaptionDataset``). Output: [{"id", "video", "frames", "caption"}] in item order."""
+    from .eval_dataset import VideoRegionCaptionDataset
+    ap = base_parser("Video region captioning with Grasp Any Region models (VideoRefer-style, MI355X-native path).",
+                     "HaochenWang/GAR-8B", "gar_8b_video", "evaluation/VideoRefer-Bench/videos")
+    ap.set_defaults(max_num_tiles=8)
+    ap.add_argument("--num_frames", type=int, default=8)
+    args = ap.parse_args(argv)
+    if not 1 <= args.num_frames <= 8:
+        raise SystemExit("--num_frames must be in 1..8 (the video replay path has 8 frame tokens)")
+    model, processor, dtype, device, rank, world = load(args)
+    data = json.load(open(args.anno_file))
+    if args.limit:
+        data = data[:args.limit]
+    exts = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+    local = []
+    for idx in dp.shard_indices(len(data), rank, world):
+        item = data[idx]
+        if "frames" in item:
+            names = [os.path.join(args.image_folder, f) for f in item["frames"]]
+        else:
+            vdir = os.path.join(args.image_folder, item["video"])
+            names = [os.path.join(vdir, f) for f in sorted(os.listdir(vdir)) if f.lower().endswith(exts)]
+        per_frame = {}
+        if "masks" in item:
+            per_frame = {int(k): v for k, v in item["masks"].items()}
+        else:
+            for obj in item["annotation"][:1]:                      # one object per item (one caption)
+                per_frame = {int(k): v["segmentation"] for k, v in obj.items()}
+        annotated = sorted(k for k in per_frame if 0 <= k < len(names))
+        if not annotated:
+            raise ValueError(f"item {item.get('id', idx)}: no annotated frame inside the clip")
+        keep = [annotated[i] for i in sample_frame_indices(len(annotated), args.num_frames)]
+        frames, masks = [], []
+        for k in keep:
+            img = Image.open(names[k]).convert("RGB")
+            seg = per_frame[k]
+            seg = ast.literal_eval(seg) if isinstance(seg, str) else seg
+            m = rle.from_polygons(seg, img.height, img.width) if isinstance(seg, list) else rle.decode(seg)
+            frames.append(img)
+            masks.append(m.astype(bool))
+        kw = {"question": item["question"]} if item.get("question") else {}
+        ds = VideoRegionCaptionDataset(frames, masks, processor, data_dtype=dtype, device=device, **kw)
+        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
+        print(text, flush=True)
+        local.append((idx, {"id": item.get("id", idx), "video": item.get("video"), "frames": keep, "caption": text}))
+    outputs = _gather(local, rank, world)
+    if outputs is None:
+        return None
+    out_dir = args.output_dir or "evaluation/VideoRefer-Bench/model_outputs"
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{args.cache_name}.json")
+    json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    print(f"Cache name: {args.cache_name}")
+    return path

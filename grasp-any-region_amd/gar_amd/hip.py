@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgar_hip.so")
 GAR_F32, GAR_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GarError(RuntimeError):
@@ -48,7 +48,9 @@ SIGNATURES = {
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
     "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
     "gar_pool2x2":([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
-    "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp], _i),
+    "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "gar_pool_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp], _i),
+    "gar_roi_replay_inplace": ([_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "gar_embed_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp], _i),
     "gar_roi_replay": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _vp], _i),
     "gar_roi_replay_batched": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),

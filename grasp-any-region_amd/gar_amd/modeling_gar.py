@@ -258,8 +258,10 @@ class GARModel:
 
     # ---- vision tower + projector (A1-A6) -----------------------------------------------------------------------------
     @_on_model_device
-    def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None):
-        """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l]."""
+    def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None,
+                           pooled: bool = True):
+        """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l].
+        ``pooled=False`` stops after the projector and returns its [Tt * tokens, C_l] output (cls rows included)."""
         cfg = self.config
         v = cfg.mllm_config.vision_config
         C_l = cfg.mllm_config.text_config.hidden_size
@@ -318,18 +320,23 @@ class GARModel:
         ops.gemm(x2, self.pj["w1"], p1, hip.EPI_BIAS_GELU, bias=self.pj["b1"])
         p2 = self._buf(key, "p2", (Tt * N, C_l))
         ops.gemm(p1, self.pj["w2"], p2, hip.EPI_BIAS, bias=self.pj["b2"])
+        if cfg.mllm_config.projector_pooling_ratio != 2:
+            raise hip.GarError("projector_pooling_ratio != 2 is not built")
+        if not pooled:
+            return p2                       # generate(): pooled on the way into the sequence (gar_pool_assemble)
         P = cfg.pooled_side
         feats = self._buf(key, "feats", (Tt, P * P, C_l))
-        if cfg.mllm_config.projector_pooling_ratio == 2:
-            ops.pool2x2(p2, feats, v.grid, in_tile_tokens=N, in_token_offset=self.npt)
-        else:
-            raise hip.GarError("projector_pooling_ratio != 2 is not built")
+        ops.pool2x2(p2, feats, v.grid, in_tile_tokens=N, in_token_offset=self.npt)
         return feats
 
     # ---- inputs_embeds: embedding + placeholder scatter + RoI replay (A7-A11) -----------------------------------------
     @_on_model_device
     def build_inputs_embeds(self, input_ids, feats, bboxes, aspect_ratios, tiles_per_sample: int, validate=True,
-                            video_frame_tokens: Optional[Sequence[int]] = None):
+                            video_frame_tokens: Optional[Sequence[int]] = None, proj: Optional[torch.Tensor] = None):
+        """``feats`` [B*tiles, P*P, C] pooled features (embed_assemble + replay from the feature tensor), or — what
+        ``generate`` uses — ``proj``: the un-pooled projector output of ``get_image_features(pooled=False)``; then the
+        2x2 pool runs on the way into the sequence and the replay reads the pooled rows back from it (one read of the
+        projector output + one write of the sequence per region: SURVEY.md section 8d's algorithmic bytes)."""
         cfg = self.config
         B, S = input_ids.shape
         C_l = cfg.mllm_config.text_config.hidden_size
@@ -351,9 +358,17 @@ class GARModel:
         counts = self._buf(key, "counts", (B,), torch.int32)
         spans = self._buf(key, "spans", (B, len(crop_ids), 2), torch.int32)
         embeds = self._buf(key, "embeds", (B, S, C_l))
-        ops.placeholder_scan(ids, cfg.mllm_config.image_token_id, crop_ids_dev, slot, counts, spans)
         n_rows = tiles_per_sample * P * P
-        ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
+        rank_pos = None
+        if proj is not None:
+            rank_pos = self._buf(key, "rank_pos", (B, n_rows), torch.int32)
+            rank_pos.zero_()                # ranks without a placeholder (count mismatch) must still index inside the row
+        ops.placeholder_scan(ids, cfg.mllm_config.image_token_id, crop_ids_dev, slot, counts, spans, rank_pos)
+        if proj is not None:
+            v = cfg.mllm_config.vision_config
+            ops.pool_assemble(ids, slot, self.E, proj, embeds, tiles_per_sample, v.grid, v.num_patches + self.npt, self.npt)
+        else:
+            ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
         if validate:
             # reference errors (modeling_perception_lm.py:309-315, modeling_gar.py:356-360) need the counts on the host
             cnt = counts.tolist()
@@ -390,8 +405,11 @@ class GARModel:
                 # image: map = tiles 1.. (thumbnail dropped, modeling_gar.py:351); video: map = frame ci only
                 jobs.append((b, ci, ci if video else 1, ncw, nch, *roi, ss))
         if jobs:         # every crop token of every sample in one launch (the roi table is the only H2D copy)
-            ops.roi_replay_batched(feats, embeds, spans, ops.roi_jobs_tensor(jobs, self.device), len(crop_ids),
-                                   tiles_per_sample, P, C_l, S, 2, True)
+            jt = ops.roi_jobs_tensor(jobs, self.device)
+            if proj is not None:
+                ops.roi_replay_inplace(embeds, spans, rank_pos, jt, len(crop_ids), P, C_l, S, 2, True)
+            else:
+                ops.roi_replay_batched(feats, embeds, spans, jt, len(crop_ids), tiles_per_sample, P, C_l, S, 2, True)
         return embeds
 
     # ---- Llama (A12) --------------------------------------------------------------------------------------------------
@@ -559,10 +577,10 @@ class GARModel:
             b1 = min(B, b0 + chunk)
             ids_c = input_ids[b0:b1]
             if pixel_values is not None:
-                feats = self.get_image_features(pv[b0:b1], None if gm is None else gm[b0:b1])
+                proj = self.get_image_features(pv[b0:b1], None if gm is None else gm[b0:b1], pooled=False)
                 ar_c = None if aspect_ratios is None else aspect_ratios[b0:b1]
-                embeds = self.build_inputs_embeds(ids_c, feats, bboxes[b0:b1], ar_c, tiles, validate,
-                                                  video_frame_tokens if feature_replay_video else None)
+                embeds = self.build_inputs_embeds(ids_c, None, bboxes[b0:b1], ar_c, tiles, validate,
+                                                  video_frame_tokens if feature_replay_video else None, proj=proj)
             else:
                 embeds = self._buf(("emb", b1 - b0, S), "embeds", (b1 - b0, S, cfg.mllm_config.text_config.hidden_size))
                 ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)

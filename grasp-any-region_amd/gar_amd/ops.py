@@ -208,12 +208,35 @@ def pool2x2(x, y, g: int, in_tile_tokens: int = 0, in_token_offset: int = 0):
     return y
 
 
-def placeholder_scan(input_ids, image_token_id, crop_ids_dev, slot, counts, spans):
+def placeholder_scan(input_ids, image_token_id, crop_ids_dev, slot, counts, spans, rank_pos=None):
+    """rank_pos (optional) int32 [B, n_rows]: position of the image token of rank r (inverse of ``slot``)."""
     B, S = input_ids.shape
     assert input_ids.dtype == torch.int64 and input_ids.is_contiguous()
     check(lib().gar_placeholder_scan(ptr(input_ids), B, S, int(image_token_id), ptr(crop_ids_dev),
-                                     crop_ids_dev.numel(), ptr(slot), ptr(counts), ptr(spans), stream()),
-          "gar_placeholder_scan")
+                                     crop_ids_dev.numel(), ptr(slot), ptr(counts), ptr(spans), ptr(rank_pos),
+                                     0 if rank_pos is None else rank_pos.shape[1], stream()), "gar_placeholder_scan")
+
+
+def pool_assemble(input_ids, slot, E, proj, out, tiles_per_sample, g, in_tile_tokens=0, in_token_offset=0):
+    """out [B,S,C] = embedding rows, image-token rows = 2x2 mean of the projector output ``proj`` [B*tiles*in_tile_tokens, C]
+    (pool2x2 + embed_assemble in one pass; the pooled features stay inside ``out``)."""
+    B, S = input_ids.shape
+    C_ = E.shape[1]
+    n_img = B * tiles_per_sample * (g // 2) ** 2
+    # algorithmic bytes (SURVEY.md section 8d): the grid rows of the projector output read once + the sequence written once
+    _timed("pool_assemble", (4 * n_img * C_ + out.numel()) * out.element_size(), lambda: check(
+        lib().gar_pool_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(proj), ptr(out), B, S, C_,
+                                tiles_per_sample, g, in_tile_tokens, in_token_offset, E.shape[0], stream()),
+        "gar_pool_assemble"))
+
+
+def roi_replay_inplace(embeds, spans, rank_pos, jobs, n_crop, P, Cc, S, sampling_ratio=2, aligned=True):
+    """batched RoI replay reading the pooled features from the image-token rows of ``embeds`` (see pool_assemble)."""
+    n = jobs.numel() // 40
+    _timed("roi_replay", n * (P * P + 16) * Cc * embeds.element_size(), lambda: check(
+        lib().gar_roi_replay_inplace(dtype_code(embeds.dtype), ptr(embeds), ptr(spans), ptr(rank_pos), rank_pos.shape[1],
+                                     ptr(jobs), n, n_crop, P, Cc, S, sampling_ratio, int(aligned), stream()),
+        "gar_roi_replay_inplace"))
 
 
 def embed_assemble(input_ids, slot, E, feats, out, n_feat_rows):

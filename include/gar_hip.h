@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 2
+#define GAR_ABI_VERSION 3
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -153,7 +153,19 @@ int gar_pool2x2(int dtype, const void* x, void* y, int T, int g, int C, int in_t
  * sync-free: slot[s] = rank of s among image tokens of its row or -1; counts[b] = #image tokens;
  * spans[b][c] = (min index, max index) of crop token c or (-1,-1). input_ids int64 [B,S]. */
 int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int64_t image_token_id, const int64_t* crop_ids,
-                         int n_crop, int32_t* slot, int32_t* counts, int32_t* spans, gar_stream_t stream);
+                         int n_crop, int32_t* slot, int32_t* counts, int32_t* spans, int32_t* rank_pos, int rank_stride,
+                         gar_stream_t stream);
+/* rank_pos (nullable) [B, rank_stride]: the inverse of slot — position of the image token of rank r (ranks >= rank_stride
+ * are dropped); what gar_roi_replay_inplace reads pooled features through. */
+
+/* PerceptionLMAdaptiveAvgPooling + nn.Embedding + masked_scatter in one pass (modeling_perception_lm.py:47-60,
+ * modeling_gar.py:332,341-346): out[b,s,:] = slot[b,s] < 0 ? E[id] : 2x2 mean of the projector output `proj`
+ * [B * tiles_per_sample * in_tile_tokens, C] at pooled token slot[b,s] (tile = slot / (g/2)^2; the g x g grid of a tile
+ * starts at its row in_token_offset, which drops a cls row as gar_pool2x2 does). The pooled features are not
+ * materialised; gar_roi_replay_inplace reads them back from `out`. */
+int gar_pool_assemble(int dtype, const int64_t* input_ids, const int32_t* slot, const void* E, const void* proj, void* out,
+                      int B, int S, int C, int tiles_per_sample, int g, int in_tile_tokens, int in_token_offset,
+                      int64_t vocab, gar_stream_t stream);
 
 /* nn.Embedding + masked_scatter (modeling_gar.py:332,341-346): out[b,s,:] = slot<0 ? E[id] : feats[b][slot].
  * feats [B, n_feat_rows, C] */
@@ -185,10 +197,18 @@ int gar_roi_replay_batched(int dtype, const void* feats, void* embeds, const int
                            int n_jobs, int n_crop, int tiles_per_sample, int P, int C, int S, int sampling_ratio,
                            int aligned, gar_stream_t stream);
 
+/* The batched replay reading the pooled features IN PLACE: after gar_pool_assemble the pooled token of rank r of sample b
+ * is row rank_pos[b][r] of embeds[b] (rank = tile * P*P + token; rank_pos from gar_placeholder_scan), so the merged map
+ * of modeling_gar.py:350-352 is addressed inside the sequence itself and no [tiles, P*P, C] feature tensor exists. The
+ * rows it writes (crop-token spans) are disjoint from the rows it reads (image-token rows). */
+int gar_roi_replay_inplace(int dtype, void* embeds, const int32_t* spans, const int32_t* rank_pos, int rank_stride,
+                           const gar_roi_job* jobs, int n_jobs, int n_crop, int P, int C, int S, int sampling_ratio,
+                           int aligned, gar_stream_t stream);
+
 /* GPU-side preprocessing (PerceptionLMImageProcessorFast.resize -> _split -> rescale_and_normalize,
  * image_processing_perception_lm_fast.py:268-372; NEAREST for the visual-prompt id matrix, eval_dataset.py:122-139).
  * src: uint8 RGB image [H, W, 3] on the device. Separable antialiased bicubic: pass 1 (horizontal) writes fp32
- * tmp [3, H, Wout]; pass 2 (vertical) rounds half-to-even, clamps to [0,255], normalises ((v/255)-mean)/std and
+ * tmp [3, H, Wout]; pass 2 (vertical) rounds half-to-even, clamps to [0,255], normalises (v - 255 mean) / (255 std) (HF fused rescale_and_normalize) and
  * writes tiles out[tile0 + (yo/ts)*ncw + (xo/ts)][c][yo%ts][xo%ts] in `dtype`. Tap tables (first source index,
  * tap count, weights [n_out, kmax]) come from the host. Accumulation order: t = s[0]*w[0]; t = fma(s[j], w[j], t). */
 int gar_resize_bicubic_h(const uint8_t* src, float* tmp, int H, int W, int Wout, const int32_t* xmin,

@@ -104,3 +104,40 @@ def test_ferret_and_mdvp_loops(tmp_path):
          "--output_dir", str(tmp_path / "out"))
     res = json.load(open(tmp_path / "out" / "m.json"))
     assert [r["gt"] for r in res] == ["gt0", "gt1"] and all(isinstance(r["caption"], str) for r in res)
+
+
+def test_video_refer_loop(tmp_path):
+    """VideoRefer-style driver (A13 caller): a directory of 10 frames with per-frame RLE masks -> 8 uniformly sampled
+    frames, one tile + one crop token per frame; the loop's caption == a direct generate on the same frames."""
+    from PIL import Image
+    from gar_amd import GARConfig, rle
+    from gar_amd.bench_loops import sample_frame_indices
+    from gar_amd.eval_dataset import VideoRegionCaptionDataset
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    os.makedirs(tmp_path / "clips" / "c0")
+    n = 10
+    for f in range(n):
+        synthetic_image(70 + f, 200, 150).save(tmp_path / "clips" / "c0" / f"{f:04d}.png")
+    masks = [synthetic_mask(80 + f, 200, 150) for f in range(n)]
+    items = [{"id": "v0", "video": "c0", "annotation": [{str(f): {"segmentation": rle.encode(masks[f])} for f in range(n)}]},
+             {"id": "v1", "frames": [f"c0/{f:04d}.png" for f in (1, 4, 7)],
+              "masks": {str(k): rle.encode(masks[f]) for k, f in enumerate((1, 4, 7))}, "question": "What moves?"}]
+    anno = tmp_path / "video.json"
+    json.dump(items, open(anno, "w"))
+    _run("VideoRefer-Bench", "--anno_file", str(anno), "--image_folder", str(tmp_path / "clips"), "--cache_name", "v",
+         "--output_dir", str(tmp_path / "out"))
+    res = json.load(open(tmp_path / "out" / "v.json"))
+    keep = sample_frame_indices(n, 8)
+    assert keep[0] == 0 and keep[-1] == n - 1 and len(keep) == 8
+    assert [r["id"] for r in res] == ["v0", "v1"] and res[0]["frames"] == keep and res[1]["frames"] == [0, 1, 2]
+    cfg = GARConfig.tiny()
+    proc = GARProcessor.from_config(cfg, max_num_tiles=4).use_gpu_preprocessing("cuda:0", torch.float32)
+    model = GARModel.from_synthetic(cfg, 0, torch.float32)
+    frames = [Image.open(tmp_path / "clips" / "c0" / f"{f:04d}.png").convert("RGB") for f in keep]
+    s = VideoRegionCaptionDataset(frames, [masks[f] for f in keep], proc, data_dtype=torch.float32, device="cuda:0")[0]
+    out = model.generate(**s, generation_config=dict(max_new_tokens=8, do_sample=False,
+                                                     eos_token_id=proc.tokenizer.eos_token_id,
+                                                     pad_token_id=proc.tokenizer.pad_token_id))
+    assert res[0]["caption"] == proc.tokenizer.decode(out.sequences[0], skip_special_tokens=True).strip()

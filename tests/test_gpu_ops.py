@@ -474,6 +474,60 @@ def test_roi_replay_batched_equals_per_token_launches(dev, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("npt", [0, 1])
+def test_pool_assemble_inplace_replay_equal_the_unfused_pass(dev, dt, npt):
+    """pool_assemble + roi_replay_inplace (what generate() runs: the pooled features live only inside the sequence) ==
+    pool2x2 -> embed_assemble -> roi_replay_batched, bit for bit — with the image placeholders split into two runs
+    (rank_pos must not assume a contiguous block), a cls row to skip (npt = 1), two samples with different canvases."""
+    from gar_amd import GARConfig, ops
+    from oracle import gar_oracle as O
+    cfg = GARConfig.gar_1b()
+    P, g, Cc, B, tiles, V, ncrop = 16, 32, 128, 2, 7, 500, 5
+    N = g * g + npt
+    n_rows = tiles * P * P
+    S = n_rows + 256 + 40
+    proj = q(rnd(B * tiles * N, Cc, seed=40), dt).to(dev, dt)
+    E = q(rnd(V, Cc, seed=41), dt).to(dev, dt)
+    ids = torch.randint(0, 290, (B, S), generator=torch.Generator().manual_seed(42))
+    img_tok, crops = 300, [304, 305, 308, 310, 311]
+    ids[0, 3:3 + 1000] = img_tok                       # sample 0: two runs of placeholders
+    ids[0, 1010:1010 + n_rows - 1000] = img_tok
+    ids[0, S - 270:S - 14] = 305
+    ids[1, 10:10 + n_rows] = img_tok                   # sample 1: one run
+    ids[1, S - 280:S - 24] = 308
+    assert int((ids[0] == img_tok).sum()) == n_rows and int((ids[1] == img_tok).sum()) == n_rows
+    ids = ids.to(dev)
+    slot = torch.empty(B, S, dtype=torch.int32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    spans = torch.empty(B, ncrop, 2, dtype=torch.int32, device=dev)
+    rank_pos = torch.zeros(B, n_rows, dtype=torch.int32, device=dev)
+    ops.placeholder_scan(ids, img_tok, torch.tensor(crops, device=dev), slot, counts, spans, rank_pos)
+    pos = (ids == img_tok).nonzero()
+    assert torch.equal(rank_pos[0].cpu().long(), pos[pos[:, 0] == 0, 1].cpu())
+    canv = {0: (3, 2), 1: (2, 3)}
+    boxes = {(0, 1): (0.1, 0.2, 0.6, 0.9), (1, 2): (0.72, 0.87, 0.79, 0.92)}
+    jobs = []
+    for (b, ci), bbox in boxes.items():
+        ncw, nch = canv[b]
+        roi, ss = O.replay_roi(bbox, P * nch, P * ncw, cfg.feat_stride)
+        jobs.append((b, ci, 1, ncw, nch, *roi[1:], ss))
+    jt = ops.roi_jobs_tensor(jobs, dev)
+    # unfused
+    feats = torch.empty(B * tiles, P * P, Cc, dtype=dt, device=dev)
+    ops.pool2x2(proj, feats, g, in_tile_tokens=N, in_token_offset=npt)
+    ref = torch.empty(B, S, Cc, dtype=dt, device=dev)
+    ops.embed_assemble(ids, slot, E, feats, ref, n_rows)
+    plain = ref.clone()
+    ops.roi_replay_batched(feats, ref, spans, jt, ncrop, tiles, P, Cc, S, 2, True)
+    # fused
+    out = torch.full((B, S, Cc), 7.0, dtype=dt, device=dev)
+    ops.pool_assemble(ids, slot, E, proj, out, tiles, g, N, npt)
+    assert torch.equal(out.cpu(), plain.cpu())
+    ops.roi_replay_inplace(out, spans, rank_pos, jt, ncrop, P, Cc, S, 2, True)
+    assert torch.equal(out.cpu(), ref.cpu()) and not torch.equal(ref.cpu(), plain.cpu())
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_argmax_first_index_tiebreak_and_lookup(dev, dt):
     from gar_amd import ops
     B, V, Cc = 3, 128262, 128

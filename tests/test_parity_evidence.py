@@ -25,7 +25,7 @@ from oracle import gar_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the samples of tests/test_gpu_e2e.py (keep in sync: the GPU tests import these)
-TINY_SINGLE, TINY_MULTI, TINY_VIDEO_BASE = 3, 0, 50
+TINY_SINGLE, TINY_MULTI, TINY_VIDEO_BASE = 0, 0, 50
 TINY8B_SINGLE, TINY8B_VIDEO_BASE = 1, 70
 
 
