@@ -97,6 +97,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         stage_half(rsW, voffW, rbW, base + 128u * rbW, st + 3 * PHALF, wave);
     };
 
+#ifdef PP_DEPHASE   /* diagnostic build (tools/r2_measure3.sh): workgroups on odd XCDs (PP_DEPHASE = 1) or on odd CU slots of
+                       every XCD (2) start half a tile period late, so that one half of the chip stores while the other
+                       half computes */
+    if ((PP_DEPHASE == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1)) && total > (int)gridDim.x) {
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long d_ = (unsigned long long)p.K * 29ull;          // ~ half of (main loop + epilogue) of a tile
+        while (__builtin_amdgcn_s_memtime() - t0_ < d_) __builtin_amdgcn_s_sleep(20);
+    }
+#endif
     int v = blockIdx.x, tm, tn;
     tile_of(v, total, tiles_m, tiles_n, tm, tn);
     int m0 = tm * PBM, n0 = tn * PBM;

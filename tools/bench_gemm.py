@@ -28,7 +28,7 @@ def main():
     dev = "cuda:0"
     reps = int(os.environ.get("REPS", "5"))
     tot_f = tot_t = 0.0
-    for name, M, N, K, epi in SHAPES:
+    for name, M, N, K, epi in SHAPES[:int(os.environ.get("SHAPES", "99"))]:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
