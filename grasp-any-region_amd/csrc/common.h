@@ -95,6 +95,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaxf(x, 0.f) - 0.5f * ax * poly * e;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// bf16 kernels: hardware exp2 / rcp (1 ulp in f32) instead of expf + an IEEE division — the result is rounded to bf16 anyway
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 // ---- host side -----------------------------------------------------------------------------------------------
 void gar_set_error(const char* fmt, ...);

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const gar_gemm_params
                 if (nin >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
+                for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
                 epilogue_store<bf16_t, EPI>(p, m, (nin >> 1) + fq * 4, v);
             }
         } else {

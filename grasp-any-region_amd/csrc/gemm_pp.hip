@@ -33,6 +33,19 @@
 
 #include "gemm_epilogue.h"
 
+// Diagnostic builds only (tools/build_variant.sh, never in the product library): -DPP_NOSTORE runs the main loop without
+// the epilogue, -DPP_L2STORE makes every tile store into the first tile's (L2-resident) region.
+#ifdef PP_NOSTORE
+#define PP_DIAG_NOSTORE true
+#else
+#define PP_DIAG_NOSTORE false
+#endif
+#ifdef PP_L2STORE
+#define PP_DIAG_L2STORE true
+#else
+#define PP_DIAG_L2STORE false
+#endif
+
 #define PBM 256
 #define PBK 64
 #define PHALF (128 * 128)             // 16 KiB: 128 rows x 64 bf16
@@ -60,13 +73,39 @@ __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsi
                                              voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
 }
 
+// GELU by table (BIAS_GELU epilogue): the erf GELU of a 256 x 256 tile costs ~46 VALU cycles per element as A&S 7.1.26
+// (v_rcp + v_exp + 15 more) — 16k cycles per tile with the matrix pipes idle, 26 % of the fc1 GEMM (nostore / L2store /
+// real-store builds). A 2048-interval table of (gelu(x_k), gelu(x_k+1) - gelu(x_k)) over [-8, 8) in the 16 KiB of
+// LDS behind the two stages, filled with erff at kernel start, linearly interpolated: |error| <= h^2/8 max|gelu''| =
+// (1/128)^2 / 8 * 0.8 = 6e-6 (bf16 rounds at 4e-3 relative), 9 VALU + one ds_read_b64 per element. x >= 8 returns x.
+#define GELU_LUT_N 2048
+#define GELU_LUT_BYTES (GELU_LUT_N * 8)
+__device__ __forceinline__ float gelu_lut(float x, const char* lut) {
+    const float u = __builtin_fmaf(x, 128.0f, 1024.0f);
+    const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, 2047.99f);
+    const float fi = __builtin_floorf(uc);
+    const float2 e = *reinterpret_cast<const float2*>(lut + ((int)fi << 3));
+    const float y = __builtin_fmaf(e.y, uc - fi, e.x);
+    return x >= 8.0f ? x : y;
+}
+
 template <int EPI, bool PERMT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
     constexpr bool PERM = PERMT && EPI != GAR_EPI_SWIGLU;
     constexpr bool LDS_EPI = true;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB (+ the GELU table)
     const int total = tiles_m * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
+    const char* const glut = smem + 2 * PSTAGE;
+    if (EPI == GAR_EPI_BIAS_GELU) {       // published by the main loop's barriers long before the first epilogue reads it
+#pragma unroll
+        for (int j = 0; j < GELU_LUT_N / 512; ++j) {
+            const int k = tid + 512 * j;
+            const float x0 = -8.0f + (float)k * (1.0f / 128.0f);
+            const float g0 = gelu_erf(x0), g1 = gelu_erf(x0 + 1.0f / 128.0f);
+            *reinterpret_cast<float2*>(smem + 2 * PSTAGE + k * 8) = make_float2(g0, g1 - g0);
+        }
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const bf16_t* A = (const bf16_t*)p.A;
@@ -214,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     tl[2] = tl[3] = tl[13] = tl[14] = tl[15] = tl13p = tl2p = tl13q = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
     auto epilogue = [&]() {
-        if (p.tokens_out == -12345) {       // DEBUG (tools/bench_gemm.py only): skip the epilogue, keep acc live
+        if (PP_DIAG_NOSTORE) {              // diagnostic build (-DPP_NOSTORE, tools/build_variant.sh): skip the epilogue, keep acc live
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         if (nin < p.N) {
                             float o[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
+                            for (int r = 0; r < 4; ++r) o[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
                             epilogue_store<bf16_t, EPI>(p, m, (nin >> 1) + fq * 4, o);
                         }
                     }
@@ -327,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                     if (ok[k]) aux[k] = *reinterpret_cast<const uint4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + n);
                 } else {
                     off[k] = (int64_t)m * p.ldc + n;
-                    if (p.tokens_out == -12346) off[k] = (int64_t)(m - m0) * p.ldc + (n - n0);   // DEBUG: L2-resident stores
+                    if (PP_DIAG_L2STORE) off[k] = (int64_t)(m - m0) * p.ldc + (n - n0);   // diagnostic build: L2-resident stores
                     if (HAS_RES && ok[k])
                         aux[k] = *reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + n);
                 }
@@ -442,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 const int tile = m / p.tokens_in;
                 return ((int64_t)tile * p.tokens_out + p.token_offset + (m - tile * p.tokens_in)) * p.ldc + n;
             }
-            if (p.tokens_out == -12346) return (int64_t)(m - m0) * p.ldc + (n - n0);     // DEBUG: L2-resident stores
+            if (PP_DIAG_L2STORE) return (int64_t)(m - m0) * p.ldc + (n - n0);     // diagnostic build: L2-resident stores
             return (int64_t)m * p.ldc + n;
         };
         auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional (clamped) so the prefetch ring carries no exec state
@@ -506,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                     }
                     if (EPI == GAR_EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
+                        for (int e = 0; e < 8; ++e) o[e] = gelu_lut(o[e], glut);
                     }
                     *reinterpret_cast<u32x4*>(priv + frow_e * 128 + (((jq * 4 + fq_e) ^ ((frow_e >> 1) & 7)) << 4)) =
                         u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
@@ -719,13 +758,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // The K loop is rotated by one phase: a taken branch costs the wave ~150 cycles of instruction refetch (measured:
         // tools/hw_probes.hip, tools/gemm_timeline.py), and phase 3's load interval (4 reads, 1 DMA) is the one with that
         // much slack — phase 0's (8 reads behind the barrier that releases the stage) is the longest.
+#ifdef PP_STOREOVERLAP   /* diagnostic build: the first K tile of an output tile is completely in LDS before the previous
+                            tile's epilogue starts (vmcnt(0) below), so its two waits are dropped — they would wait for the
+                            epilogue's STORES as well (vmcnt retires in order and counts stores) */
+#undef L0_WAIT
+#undef M0_WAIT
+#define L0_WAIT
+#define M0_WAIT
         PHASE012
+#undef L0_WAIT
+#undef M0_WAIT
+#define L0_WAIT VMWAIT(2)
+#define M0_WAIT VMWAIT(1)
+#else
+        PHASE012
+#endif
 #pragma nounroll
         for (int t = 1; t < nt; ++t) {
             PHASE3(t - 1)
             PHASE012
         }
         PHASE3(nt - 1)
+#ifdef PP_STOREOVERLAP
+        VMWAIT(0)
+#endif
 #undef PHASE012
 #undef PHASE3
         // un-stagger (row 0 waits one interval for row 1), run the epilogue of (m0, n0) on both rows at the same time
@@ -738,11 +794,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
         constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
-        if (PERM && LDS_EPI && WAVE_EPI && p.tokens_out != -12345 && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
+        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
         } else {
             if (wm == 0) __builtin_amdgcn_s_barrier();
-            if (PERM && LDS_EPI && p.tokens_out != -12345) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+            if (PERM && LDS_EPI && !PP_DIAG_NOSTORE) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
             else epilogue();
         }
 #if PP_TIMELINE == 4
@@ -777,17 +833,18 @@ static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hip
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE + GELU_LUT_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE + GELU_LUT_BYTES);
         attr_set = true;
     }
     static const int perm = [] { const char* e = getenv("GAR_GEMM_PERM"); return e ? atoi(e) : 1; }();
     static const int persist = [] { const char* e = getenv("GAR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
     const int grid = persist ? min(pm * pn, num_cus) : pm * pn;
+    constexpr int LDS = 2 * PSTAGE + (EPI == GAR_EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
     if (perm || EPI == GAR_EPI_QKV_ROPE)      // the fused qkv epilogue exists in the row-coalesced (PERM) form only
-        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
-    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, false>), dim3(grid), dim3(512), 2 * PSTAGE, s, p, pm, pn);
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), LDS, s, p, pm, pn);
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, false>), dim3(grid), dim3(512), LDS, s, p, pm, pn);
 }
 
 // returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel

@@ -231,7 +231,7 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
             for (int q = 0; q < NT / 2; ++q) {
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(v[2 * q][r]) * v[2 * q + 1][r];
+                for (int r = 0; r < 4; ++r) o[r] = silu_fast(v[2 * q][r]) * v[2 * q + 1][r];
                 if (n0 + q * 32 < p.N) epilogue_store<bf16_t, EPI>(p, m, (n0 >> 1) + q * 16 + fq * 4, o);
             }
         } else {

@@ -14,12 +14,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+HASH_ENV = dict(os.environ, PYTHONHASHSEED="0")     # the multi-region prompt order is a Python set's iteration order
+
+
 def _run(script, *args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluation", script, "inference.py"), "--synthetic_weights",
                         "--model_name_or_path", "tiny", "--data_type", "fp32", "--max_num_tiles", "4",
-                        "--max_new_tokens", "8", *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--max_new_tokens", "8", *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env=HASH_ENV)
     assert r.returncode == 0, r.stderr[-3000:]
     return r.stdout
+
+
+def _set_order(question):
+    """the order in which a PYTHONHASHSEED=0 process iterates the set of prompt tokens of `question` (what the loop's
+    MultiRegionDataset did in its subprocess)."""
+    code = "import re,sys,json; print(json.dumps(list(set(re.findall(r'<Prompt\\d+>', sys.argv[1])))))"
+    r = subprocess.run([sys.executable, "-c", code, question], capture_output=True, text=True, env=HASH_ENV)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout)
 
 
 def test_gar_bench_and_dlc_bench_loops(tmp_path):
@@ -57,7 +69,8 @@ def test_gar_bench_and_dlc_bench_loops(tmp_path):
     pt = [f"<Prompt{i}>" for i in range(cfg.prompt_numbers)] + ["<NO_Prompt>"]
     s = MultiRegionDataset(image=Image.open(tmp_path / it["image"]), masks=masks, question_str=gar_bench_question(it, "vqa"),
                            processor=proc, prompt_number=cfg.prompt_numbers, visual_prompt_tokens=pt,
-                           data_dtype=torch.float32, device="cuda:0")[0]
+                           data_dtype=torch.float32, device="cuda:0",
+                           prompt_order=_set_order(gar_bench_question(it, "vqa")))[0]
     o = model.generate(**s, generation_config=dict(max_new_tokens=8, do_sample=False, eos_token_id=proc.tokenizer.eos_token_id,
                                                    pad_token_id=proc.tokenizer.pad_token_id))
     txt = proc.tokenizer.decode(o.sequences[0], skip_special_tokens=False).strip().replace("<|eot_id|>", "")

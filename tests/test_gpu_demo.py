@@ -15,7 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(script, *args):
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "grasp-any-region_amd")]))
+    # PYTHONHASHSEED: the multi-region prompt order is the iteration order of a Python set of "<PromptK>" strings, in
+    # the reference (evaluation/eval_dataset.py:205-212) and here — two processes only agree under the same hash seed
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "grasp-any-region_amd")]),
+               PYTHONHASHSEED="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "demo", script), "--synthetic_weights", "--model_name_or_path",
                         "tiny", "--data_type", "fp32", "--max_num_tiles", "4", "--max_new_tokens", "12", *args],
                        capture_output=True, text=True, timeout=600, env=env, cwd=os.path.join(ROOT, "demo"))

@@ -8,7 +8,8 @@ from parity_util import F32_LOGIT_TOL, assert_discriminating      # 2e-4 * max|l
 
 pytestmark = pytest.mark.gpu
 
-BF16_FEAT_TOL = 3e-2      # relative L2 error of image features / logits in bf16 mode vs the f32 oracle
+BF16_FEAT_TOL = 3e-2      # relative L2 error of image features in bf16 mode vs the f32 oracle
+BF16_LOGIT_TOL = 4e-2     # ... of first-token logits (two more layers of bf16 rounding on top of the features)
 # sample indices whose oracle sequences are asserted discriminating on the CPU (tests/test_parity_evidence.py)
 TINY_SINGLE, TINY_MULTI, TINY_VIDEO_BASE = 0, 0, 50
 TINY8B_SINGLE, TINY8B_VIDEO_BASE = 1, 70
@@ -143,7 +144,7 @@ def test_bf16_against_f32_oracle_tiny(tiny):
     m = GARModel(cfg, W, torch.bfloat16)
     out = m.generate(**s, max_new_tokens=8, return_logits=True)
     lg = out.logits.cpu()
-    assert _rel_l2(lg[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
+    assert _rel_l2(lg[:, 0], ref_logits[:, 0]) < BF16_LOGIT_TOL
     # top-1 agreement wherever the f32 margin exceeds the measured bf16 logit error
     err = float((lg[:, 0] - ref_logits[:, 0]).abs().max())
     top2 = ref_logits[:, 0].topk(2).values
@@ -260,7 +261,7 @@ def test_gar8b_structure_tiny(dtype):
         _check_f32(out, ref_seq, ref_logits, "graph")
         _check_f32(m.generate(**s, max_new_tokens=12, return_logits=True, use_graph=False), ref_seq, ref_logits, "eager")
     else:
-        assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
+        assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_LOGIT_TOL
     g = m.generate(**s, max_new_tokens=ref_seq.shape[1])
     assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
 
@@ -282,7 +283,7 @@ def test_bf16_gar8b_dims_one_layer():
     ref_seq, ref_logits = _oracle(Wq, cfg, s, 2, attn_impl="sdpa")
     m = GARModel(cfg, W, torch.bfloat16)
     out = m.generate(**s, max_new_tokens=2, return_logits=True)
-    assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_FEAT_TOL
+    assert _rel_l2(out.logits.cpu()[:, 0], ref_logits[:, 0]) < BF16_LOGIT_TOL
     g = m.generate(**s, max_new_tokens=2)
     assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
 
@@ -430,8 +431,8 @@ def test_from_pretrained_hf_style_sharded_checkpoint(tiny, tmp_path, vision_bias
 
 # tolerances at full depth (23 ViT + 16 Llama layers): f32 rounding differences accumulate through 39 layers, stated
 # separately from the per-layer F32_LOGIT_TOL; measured values are printed by the test (pytest -s) and quoted in DESIGN.md
-FULL_DEPTH_F32_TOL = 1e-3
-FULL_DEPTH_BF16_REL_L2 = 6e-2
+FULL_DEPTH_F32_TOL = 2e-4     # measured 8.3e-6
+FULL_DEPTH_BF16_REL_L2 = 6e-2   # measured: first token 4.1e-2, worst of 64 steps 4.8e-2, top-1 agreement 0.906
 
 
 def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Micro-benchmark of the bf16 GEMM kernels on the benchmark's shapes (random data, HIP-event timing).
-GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel. Diagnostic rows: "nostore" = main loop
-only (epilogue skipped), "L2store" = every tile stores into the first tile's region (epilogue executed, no HBM write-back)
-— the decomposition quoted in DESIGN.md section 9."""
+GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel. The decomposition quoted in DESIGN.md
+section 9 ("nostore" = main loop only, "L2store" = every tile stores into the first tile's L2-resident region) comes from
+diagnostic builds of the library: tools/build_variant.sh nostore gemm_pp -DPP_NOSTORE (or l2store / -DPP_L2STORE), then
+GAR_HIP_LIB=.../variants/libgar_hip_nostore.so python tools/bench_gemm.py."""
 import os
 import sys
 
@@ -18,9 +19,7 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
           ("llm gate/up", 37744, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 37744, 2048, 8192, hip.EPI_RES),
           ("square 8k", 8192, 8192, 8192, hip.EPI_NONE),
           ("proj none", 139400, 1024, 1024, hip.EPI_NONE), ("proj bias", 139400, 1024, 1024, hip.EPI_BIAS),
-          ("qkv L2store", 139400, 3072, 1024, -2), ("proj L2store", 139400, 1024, 1024, -2),
-          ("proj nostore", 139400, 1024, 1024, -1), ("qkv nostore", 139400, 3072, 1024, -1),
-          ("llm o nostore", 37744, 2048, 2048, -1)]
+          ("qkv none", 139400, 3072, 1024, hip.EPI_NONE), ("llm o none", 37744, 2048, 2048, hip.EPI_NONE)]
 
 
 def main():
@@ -33,12 +32,6 @@ def main():
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
         kw = {}
-        if epi == -1:                       # debug: main loop only (no epilogue)
-            epi = hip.EPI_NONE
-            kw["tokens_out"] = -12345
-        if epi == -2:                       # debug: every tile stores into the first tile's (L2-resident) region
-            epi = hip.EPI_NONE
-            kw["tokens_out"] = -12346
         if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
         if epi in (hip.EPI_BIAS_SCALE_RES, hip.EPI_RES):
