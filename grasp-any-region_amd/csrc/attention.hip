@@ -19,9 +19,6 @@
 // attention_bf16.hip: DMA-staged bf16 kernel (default for bf16); false -> use the register-staged kernel below
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s);
-// attention_bf16_v3.hip: the software-pipelined kernel (tried first)
-bool gar_attn_bf16_v3_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
-                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s);
 
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
@@ -398,13 +395,9 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
     GAR_CHECK_ARG(q_len > 0 && q_pad >= q_len && kv_stride % 64 == 0, "attention: bad lengths");
     GAR_CHECK_ARG(kv_len_dev || (kv_len > 0 && kv_len <= kv_stride && (!causal || kv_len >= q_len)),
                   "attention: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
-    GAR_CHECK_ARG(hd == 64 || hd == 128, "attention: head_dim %d not built (64, 128)", hd);
+    GAR_CHECK_ARG(hd == 64 || hd == 128 || (hd == 96 && dtype == GAR_BF16),
+                  "attention: head_dim %d not built (64, 128; 96 in bf16 only)", hd);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GAR_BF16 &&
-        gar_attn_bf16_v3_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s)) {
-        GAR_CHECK_LAUNCH();
-        return GAR_OK;
-    }
     if (dtype == GAR_BF16 &&
         gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s)) {
         GAR_CHECK_LAUNCH();

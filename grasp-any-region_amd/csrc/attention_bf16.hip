@@ -26,8 +26,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
                                                               int kv_stride, const int32_t* __restrict__ kv_len_dev) {
-    constexpr int KRS = HD * 2;                 // K tile row bytes
-    constexpr int KT = 64 * KRS;                // K tile bytes   [64 kv][HD]
+    // head_dim 96 (PE-G/14): K rows are 192 B in HBM; the LDS image keeps the 256-B row pitch of head_dim 128 (a
+    // 4-row x 256-B DMA piece per instruction; the 64 bytes past a row's 12 real chunks are filled with a repeat of
+    // chunk 11 and never read), so the fragment reads use the conflict-free head_dim-128 swizzle
+    constexpr int KRS_G = HD * 2;               // K row bytes in HBM
+    constexpr int KRS = HD == 64 ? 128 : 256;   // K row bytes in LDS
+    constexpr int KT = 64 * KRS;                // K tile bytes in LDS   [64 kv][KRS / 2]
     constexpr int VT = HD * 128;                // Vt tile bytes  [HD][64 kv]
     constexpr int NKD = HD / 16;                // QK^T k-steps
     constexpr int NDB = HD / 32;                // O^T row blocks
@@ -67,9 +71,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     if (HD == 64) {          // piece = 8 rows x 128 B
         const int row = wave * 8 + (lane >> 3);
         voffK = row * 128 + (((lane & 7) ^ key_of<128>(row)) << 4);
-    } else {                 // piece = 4 rows x 256 B
+    } else {                 // piece = 4 rows x 256 B of LDS
         const int row = wave * 4 + (lane >> 4);
-        voffK = row * 256 + (((lane & 15) ^ key_of<256>(row)) << 4);
+        const int cl = (lane & 15) ^ key_of<256>(row);                    // logical 16-byte chunk this lane fetches
+        voffK = row * KRS_G + (min(cl, KRS_G / 16 - 1) << 4);
     }
     {
         const int row = wave * 8 + (lane >> 3);      // Vt piece = 8 d-rows x 128 B (64 kv)
@@ -78,12 +83,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     auto stage = [&](int t, int buf) {
         char* ks = smem + buf * (KT + VT);
         char* vs = ks + KT;
-        const unsigned kbase = (unsigned)t * 64u * KRS;                 // 64 kv rows per tile
+        const unsigned kbase = (unsigned)t * 64u * KRS_G;               // 64 kv rows per tile
         const unsigned vbase = (unsigned)t * 128u;                      // 64 kv columns
 #pragma unroll
         for (int i = 0; i < KI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
-                                                     voffK + (int)(kbase + (unsigned)i * 4096u), 0, 0, 0);
+                                                     voffK + (int)(kbase + (unsigned)i * (4096u / KRS) * KRS_G), 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < VI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
@@ -231,12 +236,13 @@ bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O,
     if (!mode) return false;
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
-    const int lds = 2 * (64 * hd * 2 + hd * 128);
+    const int lds = 2 * (64 * (hd == 64 ? 128 : 256) + hd * 128);
 #define LAUNCH_V2(HD_, C_)                                                                                            \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,       \
                        (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev)
     if (hd == 64) { if (causal) LAUNCH_V2(64, true); else LAUNCH_V2(64, false); }
     else if (hd == 128) { if (causal) LAUNCH_V2(128, true); else LAUNCH_V2(128, false); }
+    else if (hd == 96) { if (causal) LAUNCH_V2(96, true); else LAUNCH_V2(96, false); }
     else return false;
 #undef LAUNCH_V2
     return true;

@@ -4,6 +4,25 @@
 
 #include "common.h"
 
+// No implicit FMA contraction in this file: hipcc's default (-ffp-contract=fast) fused the two rows of norm2_kernel
+// differently — a row's LayerNorm then depended (by one bf16 ulp, in a handful of elements per million) on whether it was
+// the first or the second row of its wave, i.e. on the position of its sample in the batch (found with two identical
+// samples in one batch, tools/debug_vit_bisect.py). Every fused multiply-add below is an explicit __fmaf_rn, written
+// once (ln_out / rms_out / the accumulation helpers) and used by both kernels.
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float ln_out(float v, float mean, float rstd, float w, float b) {
+    return __fmaf_rn((v - mean) * rstd, w, b);
+}
+template <typename T>
+__device__ __forceinline__ float rms_out(float v, float rstd, float w) {
+    float n = v * rstd;
+    // HF LlamaRMSNorm: weight * hidden.to(input_dtype) -> the normalised value is rounded to the storage dtype before the
+    // weight multiply
+    if (sizeof(T) == 2) n = bf2f(f2bf(n));
+    return w * n;
+}
+
 // MAXC = register-cached chunks of 512 elements (rows up to 512*MAXC stay in registers: one HBM read); instantiated
 // for 2 / 4 / 8 so short rows (ViT D=1024) keep the VGPR count — and with it the occupancy that hides HBM latency — low
 
@@ -26,7 +45,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
             if (c < nchunk && i < D) {
                 ld8(xr + i, v[c]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += RMS ? v[c][e] * v[c][e] : v[c][e];
+                for (int e = 0; e < 8; ++e) s = RMS ? __fmaf_rn(v[c][e], v[c][e], s) : s + v[c][e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
@@ -37,7 +56,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
             float t[8];
             ld8(xr + i, t);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += RMS ? t[e] * t[e] : t[e];
+            for (int e = 0; e < 8; ++e) s = RMS ? __fmaf_rn(t[e], t[e], s) : s + t[e];
         }
     }
     s = wave_sum(s);
@@ -53,7 +72,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
                 const int i = c * 512 + lane * 8;
                 if (c < nchunk && i < D) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+                    for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q = __fmaf_rn(d, d, q); }
                 }
             }
         } else {
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
                 float t[8];
                 ld8(xr + i, t);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = t[e] - mean; q += d * d; }
+                for (int e = 0; e < 8; ++e) { const float d = t[e] - mean; q = __fmaf_rn(d, d, q); }
             }
         }
         q = wave_sum(q);
@@ -72,18 +91,12 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
         ld8(w + i, ww);
         if (RMS) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float n = t[e] * rstd;
-                // HF LlamaRMSNorm: weight * hidden.to(input_dtype) -> the normalised value is rounded to the storage
-                // dtype before the weight multiply
-                if (sizeof(T) == 2) n = bf2f(f2bf(n));
-                o[e] = ww[e] * n;
-            }
+            for (int e = 0; e < 8; ++e) o[e] = rms_out<T>(t[e], rstd, ww[e]);
         } else {
             float bb[8];
             ld8(b + i, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (t[e] - mean) * rstd * ww[e] + bb[e];
+            for (int e = 0; e < 8; ++e) o[e] = ln_out(t[e], mean, rstd, ww[e], bb[e]);
         }
         st8(yr + i, o);
     };
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(256) void norm2_kernel(const T* __restrict__ x, T* 
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[r] += RMS ? v[r][c][e] * v[r][c][e] : v[r][c][e];
+            for (int e = 0; e < 8; ++e) s[r] = RMS ? __fmaf_rn(v[r][c][e], v[r][c][e], s[r]) : s[r] + v[r][c][e];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s[0] += __shfl_xor(s[0], o, 64);
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(256) void norm2_kernel(const T* __restrict__ x, T* 
             for (int c = 0; c < NC; ++c) {
                 if (c * 512 + lane * 8 < D) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[r][c][e] - mean[r]; q[r] += d * d; }
+                    for (int e = 0; e < 8; ++e) { const float d = v[r][c][e] - mean[r]; q[r] = __fmaf_rn(d, d, q[r]); }
                 }
             }
         }
@@ -179,15 +192,8 @@ __global__ __launch_bounds__(256) void norm2_kernel(const T* __restrict__ x, T* 
             if (i >= D) continue;
             float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (RMS) {
-                    float n = v[r][c][e] * rstd[r];
-                    if (sizeof(T) == 2) n = bf2f(f2bf(n));      // HF LlamaRMSNorm rounding point (see norm_kernel)
-                    o[e] = ww[c][e] * n;
-                } else {
-                    o[e] = (v[r][c][e] - mean[r]) * rstd[r] * ww[c][e] + bb[c][e];
-                }
-            }
+            for (int e = 0; e < 8; ++e)
+                o[e] = RMS ? rms_out<T>(v[r][c][e], rstd[r], ww[c][e]) : ln_out(v[r][c][e], mean[r], rstd[r], ww[c][e], bb[c][e]);
             st8(yr + i, o);
         }
     }

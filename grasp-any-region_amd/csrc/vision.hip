@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void vit_qkv_post_kernel(const T* __restrict__
                                                            T* __restrict__ K, T* __restrict__ Vt, int N, int npt, int H,
                                                            int Npad, float q_scale) {
     constexpr int LPT = HD / 8;                 // lanes per token
-    constexpr int TPP = 256 / LPT;              // tokens per pass
     __shared__ T vs[64 * (HD + 2)];
     const int chunks = Npad / 64;
     const int ch = blockIdx.x % chunks;
@@ -111,9 +110,8 @@ __global__ __launch_bounds__(256) void vit_qkv_post_kernel(const T* __restrict__
     const int t = blockIdx.x / (chunks * H);
     const int D = H * HD;
     const int tid = threadIdx.x;
-    const int d8 = (tid % LPT) * 8;
-    for (int pass = 0; pass < 64 / TPP; ++pass) {
-        const int nl = pass * TPP + tid / LPT;   // token within chunk
+    for (int idx = tid; idx < 64 * LPT; idx += 256) {       // (token within chunk, 8-element group): any HD % 8 == 0
+        const int nl = idx / LPT, d8 = (idx % LPT) * 8;
         const int n = ch * 64 + nl;
         float q[8], k[8], v[8];
         if (n < N) {
@@ -165,14 +163,14 @@ extern "C" int gar_vit_qkv_post(int dtype, const void* qkv, const float* sn, con
                                 int T_, int N, int npt, int H, int hd, int Npad, float q_scale, gar_stream_t stream) {
     GAR_CHECK_ARG(qkv && sn && cs && Q && K && Vt, "vit_qkv_post: null pointer");
     GAR_CHECK_ARG(Npad % 64 == 0 && Npad >= N && N > 0 && T_ > 0 && H > 0, "vit_qkv_post: bad shape");
-    GAR_CHECK_ARG(hd == 64 || hd == 128, "vit_qkv_post: head_dim %d not built (64, 128)", hd);
+    GAR_CHECK_ARG(hd == 64 || hd == 96 || hd == 128, "vit_qkv_post: head_dim %d not built (64, 96, 128)", hd);
     dim3 grid(T_ * H * (Npad / 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_VQP(TT, HD_)                                                                                          \
     hipLaunchKernelGGL((vit_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, sn, cs, (TT*)Q, (TT*)K,    \
                        (TT*)Vt, N, npt, H, Npad, q_scale)
-    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_VQP(bf16_t, 64); else LAUNCH_VQP(bf16_t, 128); }
-    else { if (hd == 64) LAUNCH_VQP(float, 64); else LAUNCH_VQP(float, 128); }
+    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_VQP(bf16_t, 64); else if (hd == 96) LAUNCH_VQP(bf16_t, 96); else LAUNCH_VQP(bf16_t, 128); }
+    else { if (hd == 64) LAUNCH_VQP(float, 64); else if (hd == 96) LAUNCH_VQP(float, 96); else LAUNCH_VQP(float, 128); }
 #undef LAUNCH_VQP
     GAR_CHECK_LAUNCH();
     return GAR_OK;
@@ -183,15 +181,15 @@ extern "C" int gar_vit_qkv_post(int dtype, const void* qkv, const float* sn, con
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void vit_v_transpose_kernel(const T* __restrict__ V, T* __restrict__ Vt, int N, int H,
                                                               int Npad) {
-    constexpr int LPT = HD / 8, TPP = 256 / LPT;
+    constexpr int LPT = HD / 8;
     __shared__ T vs[64 * (HD + 2)];
     const int chunks = Npad / 64;
     const int ch = blockIdx.x % chunks;
     const int h = (blockIdx.x / chunks) % H;
     const int t = blockIdx.x / (chunks * H);
-    const int D = H * HD, tid = threadIdx.x, d8 = (tid % LPT) * 8;
-    for (int pass = 0; pass < 64 / TPP; ++pass) {
-        const int nl = pass * TPP + tid / LPT, n = ch * 64 + nl;
+    const int D = H * HD, tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * LPT; idx += 256) {
+        const int nl = idx / LPT, d8 = (idx % LPT) * 8, n = ch * 64 + nl;
         float v[8];
         if (n < N) ld8(V + ((int64_t)t * N + n) * D + h * HD + d8, v);
         else {
@@ -215,13 +213,13 @@ extern "C" int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T_, i
                                    gar_stream_t stream) {
     GAR_CHECK_ARG(V && Vt, "vit_v_transpose: null pointer");
     GAR_CHECK_ARG(Npad % 64 == 0 && Npad >= N && N > 0 && T_ > 0 && H > 0, "vit_v_transpose: bad shape");
-    GAR_CHECK_ARG(hd == 64 || hd == 128, "vit_v_transpose: head_dim %d not built (64, 128)", hd);
+    GAR_CHECK_ARG(hd == 64 || hd == 96 || hd == 128, "vit_v_transpose: head_dim %d not built (64, 96, 128)", hd);
     dim3 grid(T_ * H * (Npad / 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_VT(TT, HD_) \
     hipLaunchKernelGGL((vit_v_transpose_kernel<TT, HD_>), grid, block, 0, s, (const TT*)V, (TT*)Vt, N, H, Npad)
-    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_VT(bf16_t, 64); else LAUNCH_VT(bf16_t, 128); }
-    else { if (hd == 64) LAUNCH_VT(float, 64); else LAUNCH_VT(float, 128); }
+    if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_VT(bf16_t, 64); else if (hd == 96) LAUNCH_VT(bf16_t, 96); else LAUNCH_VT(bf16_t, 128); }
+    else { if (hd == 64) LAUNCH_VT(float, 64); else if (hd == 96) LAUNCH_VT(float, 96); else LAUNCH_VT(float, 128); }
 #undef LAUNCH_VT
     GAR_CHECK_LAUNCH();
     return GAR_OK;

@@ -157,13 +157,15 @@ class GARModel:
         self.pos = d(W[VT + "pos_embed"].reshape(-1, D))
         self.norm_pre = (d(W[VT + "norm_pre.weight"]), d(W[VT + "norm_pre.bias"]))
         self.vblocks = []
-        # The attention kernels are built for head_dim 64 and 128. Other head dims (PE-G/14: 96) run zero-padded to the
-        # next built size: padded q/k/v rows of the fused qkv weight and bias and padded input columns of the output
-        # projection are zero (and the RoPE table rotates them by the identity), so scores and outputs are unchanged.
+        # The vision attention path is built for head_dim 64, 128 and — bf16 only — 96 (PE-G/14, GAR-8B). Any other head
+        # dim (and 96 in the f32 parity mode) runs zero-padded to the next built size: padded q/k/v rows of the fused qkv
+        # weight and bias and padded input columns of the output projection are zero (and the RoPE table rotates them by
+        # the identity), so scores and outputs are unchanged.
         H, hd = v.num_heads, v.head_dim
         if hd > 128:
             raise hip.GarError(f"vision head_dim {hd} > 128 is not built")
-        self.v_hd = hdp = hd if hd in (64, 128) else (64 if hd < 64 else 128)
+        native = (64, 96, 128) if self.dtype == torch.bfloat16 else (64, 128)
+        self.v_hd = hdp = hd if hd in native else (64 if hd < 64 else 128)
 
         def pad_qkv(w):          # [3*H*hd, ...] -> [3*H*hdp, ...]
             if hdp == hd:
