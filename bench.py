@@ -36,8 +36,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GAR_BENCH_BATCH", "64")),
+    ap.add_argument("--batch", type=int, default=64,
                     help="regions per step per GPU (continuous batching of independent regions)")
+    ap.add_argument("--prefill-chunk", type=int, default=16, help="regions per vision-tower / prefill pass")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="decode loop with eager launches instead of hipGraph replays (needed under rocprofv3 --pmc)")
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--max-num-tiles", type=int, default=16)
     ap.add_argument("--workload", choices=["single", "multi_region", "video"], default="single",
@@ -161,9 +164,10 @@ def main():
     W = None
     if rank == 0:
         W = synthetic_weights(cfg, seed=0)
-        model = GARModel(cfg, W, torch.bfloat16, device)
+        model = GARModel(cfg, W, torch.bfloat16, device, prefill_chunk=args.prefill_chunk)
     else:
         model = GARModel.from_shapes(cfg, torch.bfloat16, device)
+        model.prefill_chunk = args.prefill_chunk
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")
@@ -219,7 +223,8 @@ def main():
             pending.append(pool.submit(_build, i + 1))
         else:
             batch = make_batch(i)
-        out = model.generate(**batch, max_new_tokens=args.new_tokens, eos_token_id=None, validate=False)
+        out = model.generate(**batch, max_new_tokens=args.new_tokens, eos_token_id=None, validate=False,
+                             use_graph=not args.no_graph)
         return dp.gather_captions(out.sequences, dst=0)
 
     for i in range(args.warmup):
@@ -288,7 +293,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl,
-                       "regions_per_step_per_gpu": B, "tiles_per_region": tiles, "prefill_len": S,
+                       "regions_per_step_per_gpu": B, "prefill_chunk": args.prefill_chunk,
+                       "decode": "eager launches" if args.no_graph else "one hipGraph replay per token",
+                       "tiles_per_region": tiles, "prefill_len": S,
                        "replayed_rows_per_region": n_crop_rows,
                        "new_tokens": args.new_tokens, "max_num_tiles": args.max_num_tiles,
                        "inputs": "resident in HBM" if args.preprocess == "resident" else

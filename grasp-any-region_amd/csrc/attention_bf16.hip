@@ -232,8 +232,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 // returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip)
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s) {
-    static const int mode = [] { const char* e = getenv("GAR_ATTN_V2"); return e ? atoi(e) : 1; }();
-    if (!mode) return false;
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
     const int lds = 2 * (64 * (hd == 64 ? 128 : 256) + hd * 128);

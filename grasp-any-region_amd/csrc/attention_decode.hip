@@ -415,8 +415,7 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(max_splits, Hkv, B);
-    static const int lds_mode = [] { const char* e = getenv("GAR_DECODE_LDS"); return e ? atoi(e) : 1; }();
-    if (hd == 64 && lds_mode && (int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {
+    if (hd == 64 && (int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {      // DMA-staged kernel; else per-lane fragment loads
         constexpr int lds = 4 * 16384 + 4 * 8 * (64 + 2) * 4;
         static bool attr_set = false;
         if (!attr_set) {

@@ -23,7 +23,7 @@
 //     is a function of accumulator and column, fp32-staged with row-side bias / LayerScale / residual / pos-embed / RoPE
 //     otherwise); stores are 16-byte vectors, 8 rows x 128 contiguous bytes per instruction. QKV_ROPE with full sin / cos
 //     tables keeps the older workgroup-level path (epilogue_lds: four 64-row fp32 chunks, 2 rows x 512 B per instruction);
-//     SwiGLU and the PERM=0 variant store straight from the fragments.
+//     SwiGLU stores straight from the fragments.
 //   Measured (tools/gemm_timeline.py with -DPP_TIMELINE=n builds, tools/bench_gemm.py): main loop
 //     1.45-1.59 PFLOP/s at a shader clock that the power limit holds at 1.4-1.65 GHz under this load (s_memtime ticks
 //     per wall second), i.e. ~0.9 of the matrix pipes' rate at that clock; the workgroup-level epilogue cost ~21k clocks per
@@ -89,9 +89,9 @@ __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
     return x >= 8.0f ? x : y;
 }
 
-template <int EPI, bool PERMT>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
-    constexpr bool PERM = PERMT && EPI != GAR_EPI_SWIGLU;
+    constexpr bool PERM = EPI != GAR_EPI_SWIGLU;      // SwiGLU pairs (gate16 | up16) weight tiles and stores from the fragments
     constexpr bool LDS_EPI = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB (+ the GELU table)
     const int total = tiles_m * tiles_n;
@@ -273,15 +273,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
                             epilogue_store<bf16_t, EPI>(p, m, (nin >> 1) + fq * 4, o);
-                        }
-                    }
-                } else if (!PERM) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int n = n0 + wn * 64 + j * 16 + fq * 4;
-                        if (n < p.N) {
-                            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                            epilogue_store<bf16_t, EPI>(p, m, n, o);
                         }
                     }
                 } else {
@@ -830,33 +821,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 
 template <int EPI>
 static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hipStream_t s) {
+    constexpr int LDS = 2 * PSTAGE + (EPI == GAR_EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE + GELU_LUT_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PSTAGE + GELU_LUT_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    static const int perm = [] { const char* e = getenv("GAR_GEMM_PERM"); return e ? atoi(e) : 1; }();
-    static const int persist = [] { const char* e = getenv("GAR_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-    const int grid = persist ? min(pm * pn, num_cus) : pm * pn;
-    constexpr int LDS = 2 * PSTAGE + (EPI == GAR_EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
-    if (perm || EPI == GAR_EPI_QKV_ROPE)      // the fused qkv epilogue exists in the row-coalesced (PERM) form only
-        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, true>), dim3(grid), dim3(512), LDS, s, p, pm, pn);
-    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, false>), dim3(grid), dim3(512), LDS, s, p, pm, pn);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(min(pm * pn, num_cus)), dim3(512), LDS, s, p, pm, pn);   // persistent
 }
 
 // returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel
 bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
-    static const int pp_mode = [] { const char* e = getenv("GAR_GEMM_PP"); return e ? atoi(e) : 1; }();
     static const int num_cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
     const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
-    if (!pp_mode || pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
+    if (pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
     // the row-coalesced epilogue moves 16-byte vectors of C / residual / bias / gamma / pos
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if ((p.ldc % 8) != 0 || !al16(p.C) || (p.bias && !al16(p.bias)) || (p.gamma && !al16(p.gamma)) ||

@@ -248,9 +248,8 @@ template <int EPI, int MT, int NT>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     const int nb = (p.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = p.K / 64;
-    static const int staged_mode = [] { const char* e = getenv("GAR_SKINNY_LDS"); return e ? atoi(e) : 1; }();
-    // buffer descriptors address W / x with 32-bit byte offsets
-    const bool staged = staged_mode && ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) &&
+    // buffer descriptors address W / x with 32-bit byte offsets (larger operands take the per-lane fragment loads)
+    const bool staged = ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) &&
                         ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
     constexpr int MAXLDS = 139264;
     static bool attr_set = false;
@@ -297,7 +296,7 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
 template <int EPI>
 static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
     constexpr int NT0 = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
-    static const int wide = [] { const char* e = getenv("GAR_SKINNY_WIDE_N"); return e ? atoi(e) : 8192; }();
+    constexpr int wide = 8192;      // output width from which M > 16 uses 4 weight tiles per block (tools/bench_skinny.py)
     if (p.M <= 16) launch_skinny<EPI, 1, NT0>(p, s);
     else if (p.M <= 32) {
         if (p.N >= wide && !p.norm_w) launch_skinny<EPI, 2, 4>(p, s); else launch_skinny<EPI, 2, NT0>(p, s);

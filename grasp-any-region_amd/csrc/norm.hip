@@ -214,8 +214,7 @@ static int launch_norm(int dtype, const void* x, void* y, const void* w, const v
     hipLaunchKernelGGL((norm_kernel<TT, RMS, C_>), grid, block, 0, s, (const TT*)x, (TT*)y, (const TT*)w, (const TT*)b, M, \
                        D, ldx, ldy, eps)
     // bf16 rows that fit 2 register chunks and enough rows to fill the chip: two rows per wave (ViT LN 3.8 -> 4.5 TB/s)
-    static const int two_rows = [] { const char* e = getenv("GAR_NORM2"); return e ? atoi(e) : 1; }();
-    if (dtype == GAR_BF16 && two_rows && D <= 1024 && M >= 4096) {     // D = 2048 needs 152 VGPRs and gets slower
+    if (dtype == GAR_BF16 && D <= 1024 && M >= 4096) {     // D = 2048 needs 152 VGPRs and gets slower
         dim3 grid2((M + 7) / 8);
 #define LAUNCH_NORM2(C_)                                                                                       \
     hipLaunchKernelGGL((norm2_kernel<bf16_t, RMS, C_>), grid2, block, 0, s, (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)w, \

@@ -78,8 +78,11 @@ def _on_model_device(fn):
 
 
 class GARModel:
+    DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
+    FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
+
     def __init__(self, config: GARConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
-                 device: str = "cuda:0"):
+                 device: str = "cuda:0", prefill_chunk: int = 16):
         self.device = torch.device(device)
         hip.require_device(self.device.index or 0)
         self.config = config
@@ -93,8 +96,8 @@ class GARModel:
         self._graphs: Dict[tuple, object] = {}
         self._llm_lru: List[tuple] = []
         self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
-        # regions per vision-tower / prefill pass (decode serves all B at once)
-        self.prefill_chunk = int(os.environ.get("GAR_PREFILL_CHUNK", "16"))
+        # regions per vision-tower / prefill pass (decode serves all B at once); 10-16 measure within +-0.5 %
+        self.prefill_chunk = int(prefill_chunk)
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
@@ -291,7 +294,7 @@ class GARModel:
         att = self._buf(key, "att", (Tt * N, Da))
         # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
         # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
-        fused = self.dtype == torch.bfloat16 and os.environ.get("GAR_FUSED_QKV", "1") != "0"
+        fused = self.dtype == torch.bfloat16
         vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
@@ -495,10 +498,10 @@ class GARModel:
         q_scale = (hd ** -0.5) * LOG2E
         pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
         # enough (split, kv head, batch) 4-wave blocks to cover the chip: ~512 blocks = 2048 waves
-        nsplit = max(1, min(64, int(os.environ.get("GAR_DECODE_BLOCKS", "512")) // max(1, B * Hkv)))
+        nsplit = max(1, min(64, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
-        fuse = B <= int(os.environ.get("GAR_FUSE_NORM_MAXB", "16"))     # RMSNorm folded into the skinny GEMM prologue (every block redoes x*g: only pays for <= 16 rows)
+        fuse = B <= self.FUSE_NORM_MAX_BATCH     # every block redoes x*g in the prologue: only pays for <= 16 rows
         for li, ly in enumerate(self.layers):
             if fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
@@ -602,7 +605,7 @@ class GARModel:
             eos_list = [int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
             eos, eos_first = set(eos_list), (eos_list[0] if eos_list else None)
         graph = None
-        if use_graph and max_new_tokens > 1 and os.environ.get("GAR_NO_GRAPH") != "1":
+        if use_graph and max_new_tokens > 1:
             graph, graph_logits = self._decode_graph(st, B, Smax, out_tokens, skey)
         n_done = 1
         finished_at = [None] * B

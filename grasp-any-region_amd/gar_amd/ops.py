@@ -5,8 +5,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
-import os
-
 import torch
 
 from . import hip
@@ -127,9 +125,7 @@ _SINCOS_CACHE = {}
 def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
     """timm's RotaryEmbeddingCat repeats every angle for both elements of a rotated pair (repeat_interleave(2),
     SURVEY.md A.1); when the tables have that form return the compact (sin, cos)-pair table the library's fast QKV_ROPE
-    epilogue reads (include/gar_hip.h: qkv_cos == NULL), else None. Cached per table pair; GAR_QKV_COMPACT=0 disables."""
-    if os.environ.get("GAR_QKV_COMPACT", "1") == "0":
-        return None
+    epilogue reads (include/gar_hip.h: qkv_cos == NULL), else None. Cached per table pair."""
     key = (sin.data_ptr(), cos.data_ptr(), tuple(sin.shape))
     hit = _SINCOS_CACHE.get(key)
     if hit is None:
@@ -140,7 +136,8 @@ def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
     return hit[0] if hit[0] is not False else None
 
 
-def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale) -> bool:
+def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale,
+                  compact: bool = True) -> bool:
     """qkv GEMM with the front half of timm AttentionRope fused (GAR_EPI_QKV_ROPE): q / k are rotated, scaled and written
     straight into Q / K [tiles, heads, tokens_pad, hd]; v goes row-major to ``v_out`` [M, heads*hd]. Returns False when the
     library does not take this shape / dtype on the fused path (caller keeps gemm + vit_qkv_post)."""
@@ -153,7 +150,9 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     p.M, p.N, p.K = M, N, Kd
     p.epilogue = hip.EPI_QKV_ROPE
     p.bias = ptr(bias)
-    sc = _compact_sincos(sin, cos)
+    # compact=False forces the general form (independent sin / cos tables, workgroup-level epilogue) that tables without the
+    # pair structure take anyway
+    sc = _compact_sincos(sin, cos) if compact else None
     if sc is not None:         # (sin, cos) pairs [tokens, hd/2, 2]: half the table bytes, the barrier-free per-wave epilogue
         p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sc), None
     else:

@@ -644,15 +644,14 @@ def test_abi_errors_are_reported_not_thrown(dev):
         ops.gemm(a, w, torch.zeros(4, 16, device=dev))
 
 
-@pytest.mark.parametrize("npt,hd,H", [(1, 64, 16), (0, 128, 8)])
-@pytest.mark.parametrize("compact", ["1", "0"])
-def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact, monkeypatch):
+@pytest.mark.parametrize("npt,hd,H", [(1, 64, 16), (0, 128, 8), (0, 96, 16)])
+@pytest.mark.parametrize("compact", [True, False])
+def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact):
     """GAR_EPI_QKV_ROPE (q / k rotated, scaled and laid out by the qkv GEMM's epilogue + gar_vit_v_transpose) against the
     two-kernel path (GAR_EPI_BIAS GEMM -> gar_vit_qkv_post) and against an fp64 statement; the fused path rounds to
     bf16 once instead of twice, so the comparison is within bf16 rounding, not bitwise. Pad rows stay zero."""
     from gar_amd import hip, ops
-    # "1": compact (sin, cos)-pair table + barrier-free per-wave epilogue; "0": full tables + workgroup-level epilogue
-    monkeypatch.setenv("GAR_QKV_COMPACT", compact)
+    # compact: (sin, cos)-pair table + barrier-free per-wave epilogue; not compact: full tables + workgroup-level epilogue
     dt = torch.bfloat16
     T, n = 4, 1024
     N = n + npt
@@ -672,7 +671,7 @@ def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact
     Q1, K1 = (torch.zeros(T, H, Npad, hd, dtype=dt, device=dev) for _ in range(2))
     V1 = torch.full((T, H, hd, Npad), 7.0, dtype=dt, device=dev)
     vrow = torch.empty(T * N, D, dtype=dt, device=dev)
-    assert ops.gemm_qkv_rope(a, w, b, vrow, Q1, K1, sin, cos, H, hd, N, Npad, npt, qs)
+    assert ops.gemm_qkv_rope(a, w, b, vrow, Q1, K1, sin, cos, H, hd, N, Npad, npt, qs, compact=compact)
     ops.vit_v_transpose(vrow, V1, T, N, H, hd, Npad)
     # fp64 statement
     full = (a.double() @ w.double().T + b.double()).view(T, N, 3, H, hd).cpu()

@@ -179,11 +179,10 @@ def test_checkpoint_normalisation_fills_config_and_folds_bias_variants(vision_bi
         assert torch.count_nonzero(b[128:256]) == 0 and torch.equal(b[:128], W["mllm.model.vision_tower.timm_model.blocks.0.attn.qkv.bias"][:128])
 
 
-def test_compact_sincos_table_for_the_fused_rope_epilogue(monkeypatch):
+def test_compact_sincos_table_for_the_fused_rope_epilogue():
     """ops._compact_sincos: (sin, cos)-pair table only when every angle is repeated for both elements of a rotated pair
     (timm's cat layout); anything else keeps the full tables (the library then takes its general epilogue)."""
     from gar_amd import ops
-    monkeypatch.setenv("GAR_QKV_COMPACT", "1")
     ang = torch.randn(40, 32)
     sin, cos = ang.sin().repeat_interleave(2, -1).contiguous(), ang.cos().repeat_interleave(2, -1).contiguous()
     sc = ops._compact_sincos(sin, cos)
@@ -193,8 +192,6 @@ def test_compact_sincos_table_for_the_fused_rope_epilogue(monkeypatch):
     sin2 = sin.clone()
     sin2[3, 5] += 0.25                                                      # pair no longer shares its angle
     assert ops._compact_sincos(sin2, cos) is None
-    monkeypatch.setenv("GAR_QKV_COMPACT", "0")
-    assert ops._compact_sincos(sin, cos) is None
 
 
 def test_processor_with_a_real_hf_tokenizer_directory(tmp_path):

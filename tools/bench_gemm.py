@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the bf16 GEMM kernels on the benchmark's shapes (random data, HIP-event timing).
-GAR_GEMM_PP=0 selects the 128x128 kernel, default the 256x256 ping-pong kernel. The decomposition quoted in DESIGN.md
+Large problems take the 256x256 ping-pong kernel (gemm_pp.hip), small ones the 128x128 kernel. The decomposition quoted in DESIGN.md
 section 9 ("nostore" = main loop only, "L2store" = every tile stores into the first tile's L2-resident region) comes from
 diagnostic builds of the library: tools/build_variant.sh nostore gemm_pp -DPP_NOSTORE (or l2store / -DPP_L2STORE), then
 GAR_HIP_LIB=.../variants/libgar_hip_nostore.so python tools/bench_gemm.py."""
@@ -51,7 +51,7 @@ def main():
         tot_f += fl
         tot_t += ms
         print(f"{name:12s} M={M:6d} N={N:5d} K={K:4d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
-    print(f"weighted: {tot_f / tot_t / 1e9:.1f} TFLOP/s  (GAR_GEMM_PP={os.environ.get('GAR_GEMM_PP', '1')})")
+    print(f"weighted: {tot_f / tot_t / 1e9:.1f} TFLOP/s  (library: {os.environ.get('GAR_HIP_LIB', 'product')})")
 
 
 if __name__ == "__main__":
