@@ -20,10 +20,6 @@
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s);
 
-// attention_pp.hip: 8-wave ping-pong kernel for head_dim 64 (tried first)
-bool gar_attn_pp_bf16_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
-                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s);
-
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 
@@ -402,12 +398,6 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
     GAR_CHECK_ARG(hd == 64 || hd == 128 || (hd == 96 && dtype == GAR_BF16),
                   "attention: head_dim %d not built (64, 128; 96 in bf16 only)", hd);
     hipStream_t s = (hipStream_t)stream;
-    static const bool use_pp = [] { const char* e = getenv("GAR_ATTN_PP"); return !e || atoi(e) != 0; }();     // A/B while tuning
-    if (dtype == GAR_BF16 && use_pp &&
-        gar_attn_pp_bf16_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s)) {
-        GAR_CHECK_LAUNCH();
-        return GAR_OK;
-    }
     if (dtype == GAR_BF16 &&
         gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s)) {
         GAR_CHECK_LAUNCH();
