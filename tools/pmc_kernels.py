@@ -4,8 +4,10 @@ analysis needs (gfx950, 256 CUs x 4 SIMDs):
 
     python tools/pmc_kernels.py <counter_collection.csv> [<kernel_trace.csv>] > summary.json
 
-  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024)       busy matrix-pipe cycles per SIMD-cycle
-  eff_clock_GHz  = GRBM_GUI_ACTIVE / kernel duration                          (needs the kernel trace of the same run)
+  rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCD instances (a 2.0 ms launch at 1.65 GHz reads 8 x 3.3e6), and
+  SQ_VALU_MFMA_BUSY_CYCLES exactly 16 per v_mfma_f32_16x16x32_bf16 / 32 per 32x32x16 (checked against the flop count):
+  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)    busy matrix-pipe cycles per SIMD-cycle
+  eff_clock_GHz  = GRBM_GUI_ACTIVE / 8 / kernel duration                             (needs the kernel trace of the same run)
   wait / issue   = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
   lds_conflict   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   l2_hit         = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
@@ -43,10 +45,10 @@ def main(pmc_csv, trace_csv=None):
         d = {"launches": len(launches[k]), "counters": dict(c)}
         gui = c.get("GRBM_GUI_ACTIVE")
         if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-            d["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
+            d["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 1024.0)
         if gui and dur.get(k):
             d["duration_us_per_launch"] = dur[k] / ndur[k] / 1e3
-            d["eff_clock_GHz"] = gui / dur[k]
+            d["eff_clock_GHz"] = gui / 8.0 / dur[k]
         wc = c.get("SQ_WAVE_CYCLES")
         if wc:
             for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
