@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "grasp-any-region_amd")):
 
 import torch  # noqa: E402
 
-TORCH_DTYPE_MAP = dict(bf16=torch.bfloat16, fp32=torch.float32)
+from gar_amd.bench_loops import DATA_TYPE_CHOICES, TORCH_DTYPE_MAP, resolve_data_type  # noqa: E402,F401
 
 
 def base_parser(description):
@@ -19,7 +19,8 @@ def base_parser(description):
     ap.add_argument("--model_name_or_path", default="HaochenWang/GAR-1B",
                     help="checkpoint directory (config.json + *.safetensors [+ tokenizer]); with --synthetic_weights a "
                          "size name: gar_1b | gar_8b | tiny")
-    ap.add_argument("--data_type", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--data_type", choices=DATA_TYPE_CHOICES, default="bf16",
+                    help="bf16 | fp32; fp16 is refused with an explanation (no fp16 kernels)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--max_num_tiles", type=int, default=16)
@@ -35,7 +36,7 @@ def load(args):
     from gar_amd import GARConfig
     from gar_amd.modeling_gar import GARModel
     from gar_amd.processing import GARProcessor
-    dtype = TORCH_DTYPE_MAP[args.data_type]
+    dtype = resolve_data_type(args.data_type)
     torch.manual_seed(args.seed)
     if args.synthetic_weights:
         name = args.model_name_or_path if args.model_name_or_path in ("gar_1b", "gar_8b", "tiny") else "gar_1b"

@@ -322,3 +322,20 @@ def test_polygon_rasteriser_known_answers():
     assert u.sum() == 1600 + 1600 - 400
     c = rle.from_polygons([[-20.0, -20.0, 30.0, -20.0, 30.0, 30.0, -20.0, 30.0]], 64, 64)
     assert c.sum() == 30 * 30 and c[0, 0] == 1
+
+
+def test_fp16_is_parsed_and_refused_with_a_reason():
+    """The reference CLIs offer --data_type fp16 (demo/gar_with_mask.py:44); this path has bf16 / fp32 kernels only:
+    the flag parses, and is refused before anything is loaded — never silently mapped to bf16."""
+    import subprocess
+    import sys
+    from gar_amd.bench_loops import DATA_TYPE_CHOICES, resolve_data_type
+    assert DATA_TYPE_CHOICES == ["fp16", "bf16", "fp32"]
+    assert resolve_data_type("bf16") is torch.bfloat16 and resolve_data_type("fp32") is torch.float32
+    with pytest.raises(SystemExit, match="fp16 is not supported"):
+        resolve_data_type("fp16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "demo", "gar_with_mask.py"), "--image_path", "x",
+                        "--mask_path", "y", "--data_type", "fp16", "--synthetic_weights"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "fp16 is not supported" in r.stderr
