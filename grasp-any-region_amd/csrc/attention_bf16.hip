@@ -19,15 +19,6 @@ __device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
-// value held by the lane 32 away (the other half-wave): v_permlane32_swap on registers instead of a ds_bpermute round trip
-// through the LDS pipe — this exchange sits on the critical path of every kv tile (row max across the two half-waves)
-__device__ __forceinline__ float other_half(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // r[0] = [lo | lo], r[1] = [hi | hi]
-    const float lo = __builtin_bit_cast(float, (unsigned)r[0]), hi = __builtin_bit_cast(float, (unsigned)r[1]);
-    return (threadIdx.x & 32) ? lo : hi;
-}
-
 template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
 
 template <int HD, bool CAUSAL>
@@ -169,14 +160,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                         s[blk][r] = kv <= lim ? s[blk][r] : -INFINITY;
                     }
             }
-            float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mx3 = -INFINITY;     // four short chains, then a tree
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                mx0 = fmaxf(mx0, s[0][r]); mx1 = fmaxf(mx1, s[0][r + 1]);
-                mx2 = fmaxf(mx2, s[1][r]); mx3 = fmaxf(mx3, s[1][r + 1]);
-            }
-            float mx = fmaxf(fmaxf(mx0, mx1), fmaxf(mx2, mx3));
-            mx = fmaxf(mx, other_half(mx));
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
                 const float m_new = fmaxf(m_run, mx);
                 const float m_nu = m_new == -INFINITY ? 0.f : m_new;
@@ -189,15 +178,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             }
             const float m_use = m_run == -INFINITY ? 0.f : m_run;
-            float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+            float ps = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 float p[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) { ps0 += p[r]; ps1 += p[r + 1]; ps2 += p[r + 2]; ps3 += p[r + 3]; }
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     u32x4 w;
@@ -208,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                     pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
                 }
             }
-            l_run += (ps0 + ps1) + (ps2 + ps3);
+            l_run += ps;
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
                 const int row = d * 32 + l31;
@@ -227,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         __syncthreads();
     }
     // epilogue: O[b*q_len + q][head*HD + d], d = 32 db + (r&3) + 8 (r>>2) + 4 h
-    const float l_tot = l_run + other_half(l_run);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int qi = q0 + l31;
     if (qi < q_len) {
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
