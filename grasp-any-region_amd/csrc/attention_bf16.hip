@@ -11,12 +11,23 @@
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
 #define RESCALE_THR 6.0f   // log2 domain
 
+#ifdef ATTN_TIMELINE   /* diagnostic build (tools/attn_timeline.py): shader-clock stamps between the segments of the kv loop;
+                          the (b = 0, head = 0, middle q-block) workgroup writes its per-wave sums over rows 0..3 of O */
+#define TLA(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TLA(i)
+#endif
+
 typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
 typedef float f32v2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) {
     f32v2_t v = {lo, hi};
     bf16v2_t r = __builtin_convertvector(v, bf16v2_t);
     return __builtin_bit_cast(unsigned int, r);
+}
+
+__device__ __forceinline__ f32x16 zero16_c() {
+    return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 }
 
 template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
@@ -110,6 +121,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // The QK^T accumulator chains start from -m (the running max the scores are measured against) instead of 0: the MFMA
+    // delivers s - m and the softmax needs no subtraction — 32 VALU instructions fewer per kv tile in a loop whose SIMD
+    // time is (matrix pipe time + VALU issue time), see profiles/r2_attention_timeline.txt. 16 VGPRs, rewritten only
+    // when the max moves by more than 2^RESCALE_THR. Non-causal head_dim 64 (the ViT) only: +2.0 ... +3.4 % there; the
+    // causal instantiation goes from 144 to 201 VGPRs with it (-7 %), and with head_dim 96 / 128 the softmax is half as
+    // large next to the MFMAs while the accumulators leave no room (profiles/r2_attention_experiments.txt).
+    constexpr bool NEGM = HD == 64 && !CAUSAL;
+    f32x16 negm = zero16_c();
 
     int kv_end = kv_len;
     if (CAUSAL) kv_end = min(kv_len, qb * 128 + 127 + coff + 1);
@@ -129,9 +148,17 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         koff[blk] = row * KRS;
         kkey[blk] = key_of<KRS>(row);
     }
+#ifdef ATTN_TIMELINE
+    unsigned tl_t[8], tl_sum[8];
+    for (int i = 0; i < 8; ++i) tl_sum[i] = 0u;
+    unsigned tl_n = 0u;
+    const unsigned tl_begin = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
+        TLA(0)
         if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        TLA(1)
         const int kv0 = t * 64;
         const bool skip = !wave_active || (CAUSAL && kv0 > q0 + 31 + coff);     // wave-uniform
         if (!skip) {
@@ -144,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                 for (int kd = 0; kd < NKD; ++kd) {
                     const bf16x8 kf =
                         *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
                 }
             }
+            TLA(2)
             // register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
             const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
             if (need_mask) {
@@ -165,26 +193,53 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
-                const float m_new = fmaxf(m_run, mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // relative to m_base = -negm (0 while m_run is still -inf)
+            TLA(3)
+            float m_use = 0.f;                  // what is still to be subtracted from the scores
+            if (!NEGM) {
+                if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
+                    const float m_new = fmaxf(m_run, mx);
+                    const float m_nu = m_new == -INFINITY ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                }
+                m_use = m_run == -INFINITY ? 0.f : m_run;
+            } else
+            // (m_base - m_run) is 0 once the row has a finite max and +inf before: NaN / +inf also land in the branch
+            if (!__all(mx + (-negm[0] - m_run) <= RESCALE_THR)) {
+                const float m_base = -negm[0];
+                const float m_new = fmaxf(m_run, mx + m_base);
                 const float m_nu = m_new == -INFINITY ? 0.f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);
+                const float shift = m_base - m_nu;              // re-base this tile's scores on the new max
                 m_run = m_new;
                 l_run *= alpha;
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[blk][r] += shift;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_nu;
             }
-            const float m_use = m_run == -INFINITY ? 0.f : m_run;
             float ps = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 float p[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_use);
+                    ps += p[r];
+                }
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     u32x4 w;
@@ -196,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                 }
             }
             l_run += ps;
+            TLA(4)
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
                 const int row = d * 32 + l31;
@@ -209,10 +265,32 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[blk][tt], o[d], 0, 0, 0);
                     }
             }
+            TLA(5)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TLA(6)
         __syncthreads();
+        TLA(7)
+#ifdef ATTN_TIMELINE
+        if (!skip && !(CAUSAL && kv0 + 63 > q0 + coff) && kv0 + 64 <= kv_len) {     // full, unmasked tiles only
+            for (int i = 0; i < 7; ++i) tl_sum[i] += tl_t[i + 1] - tl_t[i];
+            ++tl_n;
+        }
+#endif
     }
+#ifdef ATTN_TIMELINE
+    {
+        const unsigned tl_total = (unsigned)__builtin_amdgcn_s_memtime() - tl_begin;
+        const bool writer = b == 0 && head == 0 && qb == nqb / 2;
+        if (writer && lane < 16) {
+            unsigned v = 0u;                   // dynamic register indexing would go to scratch: select with a chain
+            for (int i = 0; i < 7; ++i) v = lane == i ? tl_sum[i] : v;
+            v = lane == 7 ? tl_n : lane == 8 ? tl_total : lane == 9 ? (unsigned)ntiles : v;
+            reinterpret_cast<unsigned*>(O + (int64_t)wave * ((int64_t)Hq * HD))[lane] = v;
+        }
+        if (b == 0 && head == 0 && qb == 0) return;      // the rows the writer uses
+    }
+#endif
     // epilogue: O[b*q_len + q][head*HD + d], d = 32 db + (r&3) + 8 (r>>2) + 4 h
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int qi = q0 + l31;

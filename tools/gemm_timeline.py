@@ -17,7 +17,12 @@ def main():
     hip.require_device(0)
     dev = "cuda:0"
     # store behaviour (real / none / L2-resident) is a property of the library build: see tools/build_variant.sh
-    for name, M, N, K in [("proj", 139400, 1024, 1024), ("qkv", 139400, 3072, 1024), ("llm down", 37744, 2048, 8192)]:
+    shapes = [("proj", 139400, 1024, 1024), ("qkv", 139400, 3072, 1024), ("llm down", 37744, 2048, 8192)]
+    if os.environ.get("MORE_SHAPES"):   # does the slow start of an output tile follow the A panel being cold?
+        shapes += [("proj, A (64 MB) resident in the Infinity Cache", 32768, 1024, 1024),
+                   ("fc1: every A panel shared by 16 n-tiles", 139400, 4096, 1024),
+                   ("fc2", 139400, 1024, 4096), ("llm o", 37744, 2048, 2048)]
+    for name, M, N, K in shapes:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
