@@ -225,8 +225,10 @@ def main():
             batch = make_batch(i)
         out = model.generate(**batch, max_new_tokens=args.new_tokens, eos_token_id=None, validate=False,
                              use_graph=not args.no_graph)
+        input_flags.append(out.input_flags)             # device-side input checks: read after the timed region
         return dp.gather_captions(out.sequences, dst=0)
 
+    input_flags = []
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -241,6 +243,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
+    bad_inputs = 0
+    for f in input_flags:
+        bad_inputs |= int(f.item())
+    if bad_inputs:
+        from gar_amd.modeling_gar import describe_input_flags
+        raise SystemExit(f"bench inputs failed the device-side checks: {describe_input_flags(bad_inputs)}")
 
     if rank != 0:
         return
@@ -303,8 +311,9 @@ def main():
                        "distinct_samples": f"{min(DISTINCT_SAMPLES, args.pool * B)} distinct synthetic samples per rank, "
                                            f"repeated to fill the {B}-region batch (host bicubic sample building is slow)",
                        "validate": False,
-                       "validate_note": "generate(validate=False): the reference's image-token count / missing-bbox "
-                                        "checks (host syncs) are skipped inside the timed region",
+                       "validate_note": "generate(validate=False): the reference's image-token count / span / missing-bbox "
+                                        "checks run on the device inside the timed region and their flag is read after it "
+                                        "(0 here); only the host syncs are skipped",
                        "eos": "disabled (exactly new_tokens tokens per region)",
                        "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},

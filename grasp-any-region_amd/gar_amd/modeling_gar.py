@@ -30,6 +30,21 @@ LOG2E = 1.4426950408889634
 class GenerateOutput:
     sequences: torch.Tensor                      # [B, n_new] int64 (only new tokens, as with inputs_embeds in HF)
     logits: Optional[torch.Tensor] = None        # [B, n_new, V] when return_logits=True (tests)
+    # validate=False only: device int32 [1], OR of the INPUT_* bits below found by the device-side checks (0 = the
+    # inputs were what validate=True would have accepted). Reading it is the caller's sync; generate() itself raises on it
+    # wherever it synchronises anyway (EOS polls).
+    input_flags: Optional[torch.Tensor] = None
+
+
+INPUT_COUNT_MISMATCH, INPUT_SPAN_LENGTH, INPUT_MISSING_BBOX, INPUT_ID_RANGE = 1, 2, 4, 8
+
+
+def describe_input_flags(flags: int) -> str:
+    names = {INPUT_COUNT_MISMATCH: "image token count != image feature rows (reference: ValueError)",
+             INPUT_SPAN_LENGTH: "a crop-token span is not P*P long (the reference's splice would change the sequence length)",
+             INPUT_MISSING_BBOX: "a crop token present in input_ids has no bbox (reference: KeyError)",
+             INPUT_ID_RANGE: "input_ids outside [0, vocab)"}
+    return "; ".join(v for k, v in names.items() if flags & k)
 
 
 def _round_up(x, m):
@@ -374,6 +389,20 @@ class GARModel:
             ops.pool_assemble(ids, slot, self.E, proj, embeds, tiles_per_sample, v.grid, v.num_patches + self.npt, self.npt)
         else:
             ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
+        if not validate:
+            # the same conditions, evaluated on the device and OR-ed into a flag nobody has to wait for:
+            # what the kernels do with such inputs (clamped slots / ids, P*P rows written from the span head) is defined
+            # but not what the reference computes
+            V = self.E.shape[0]
+            present = spans[..., 1] >= 0
+            has_box = torch.tensor([[str(t) in bboxes[b] for t in crop_ids] for b in range(B)], device=self.device)
+            bad = ((counts != n_rows).any().to(torch.int32) * INPUT_COUNT_MISMATCH
+                   | (present & has_box & (spans[..., 1] - spans[..., 0] + 1 != P * P)).any().to(torch.int32) * INPUT_SPAN_LENGTH
+                   | (present & ~has_box).any().to(torch.int32) * INPUT_MISSING_BBOX
+                   | ((ids < 0) | (ids >= V)).any().to(torch.int32) * INPUT_ID_RANGE)
+            if getattr(self, "_input_flags", None) is None:
+                self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._input_flags |= bad
         if validate:
             # reference errors (modeling_perception_lm.py:309-315, modeling_gar.py:356-360) need the counts on the host
             cnt = counts.tolist()
@@ -577,6 +606,7 @@ class GARModel:
         # vision tower + prefill run over chunks of <= prefill_chunk regions (bounded activation memory, GEMM operands
         # < 4 GiB); the decode loop below then serves all B sequences of the shared KV cache in one weight pass per token
         first_logits = []
+        self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
         chunk = max(1, min(B, self.prefill_chunk))
         for b0 in range(0, B, chunk):
             b1 = min(B, b0 + chunk)
@@ -621,7 +651,10 @@ class GARModel:
             if forced_tokens is not None and n_done - 1 < forced_tokens.shape[1]:
                 st["cur"].copy_(forced_tokens[:, n_done - 1])
             if eos and (n_done % sync_every == 0 or n_done == max_new_tokens):
-                if self._all_finished(out_tokens, n_done, eos, finished_at):
+                fin = self._all_finished(out_tokens, n_done, eos, finished_at)
+                if not validate:
+                    self._raise_on_input_flags()        # the poll above synchronised already
+                if fin:
                     break
         seq = out_tokens[:, :n_done].clone()
         if eos:
@@ -635,7 +668,13 @@ class GARModel:
                         host[b][j] = pad
                 host[b] = host[b][:cut]
             seq = torch.tensor(host, dtype=torch.int64, device=self.device)
-        return GenerateOutput(sequences=seq, logits=torch.stack(all_logits, 1) if return_logits else None)
+        return GenerateOutput(sequences=seq, logits=torch.stack(all_logits, 1) if return_logits else None,
+                              input_flags=None if validate else self._input_flags)
+
+    def _raise_on_input_flags(self):
+        f = int(self._input_flags.item())
+        if f:
+            raise ValueError("generate(validate=False): " + describe_input_flags(f))
 
     @staticmethod
     def _all_finished(out_tokens, n_done, eos, finished_at) -> bool:

@@ -185,6 +185,30 @@ def test_reference_error_behaviour(tiny):
     bad["bboxes"] = [{}]
     with pytest.raises(KeyError):
         m.generate(**bad, max_new_tokens=2)
+    # validate=False skips the host syncs, not the checks: the same conditions are evaluated on the device and come
+    # back as a flag (raised at the first EOS poll when there is one)
+    from gar_amd.modeling_gar import INPUT_COUNT_MISMATCH, INPUT_ID_RANGE, INPUT_MISSING_BBOX, INPUT_SPAN_LENGTH
+    assert int(m.generate(**s, max_new_tokens=2, validate=False).input_flags.item()) == 0
+    assert m.generate(**s, max_new_tokens=2).input_flags is None
+    bad = dict(s)
+    bad["input_ids"] = s["input_ids"].clone()
+    bad["input_ids"][0, 10] = 7
+    assert int(m.generate(**bad, max_new_tokens=2, validate=False).input_flags.item()) == INPUT_COUNT_MISMATCH
+    with pytest.raises(ValueError, match="image token count"):
+        m.generate(**bad, max_new_tokens=4, validate=False, eos_token_id=0, sync_every=2)
+    bad = dict(s)
+    bad["bboxes"] = [{}]
+    assert int(m.generate(**bad, max_new_tokens=2, validate=False).input_flags.item()) == INPUT_MISSING_BBOX
+    crop = next(c for c in cfg.crop_tokens_ids if bool((s["input_ids"][0] == c).any()))
+    pos = (s["input_ids"][0] == crop).nonzero()[:, 0]
+    bad = dict(s)
+    bad["input_ids"] = s["input_ids"].clone()
+    bad["input_ids"][0, pos[-1]] = 7                  # the crop-token span is one row short
+    assert int(m.generate(**bad, max_new_tokens=2, validate=False).input_flags.item()) == INPUT_SPAN_LENGTH
+    bad = dict(s)
+    bad["input_ids"] = s["input_ids"].clone()
+    bad["input_ids"][0, 0] = cfg.mllm_config.text_config.vocab_size + 5
+    assert int(m.generate(**bad, max_new_tokens=2, validate=False).input_flags.item()) == INPUT_ID_RANGE
 
 
 def test_f32_parity_gar1b_dims_one_layer():

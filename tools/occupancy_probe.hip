@@ -6,7 +6,7 @@
 #include <stdio.h>
 
 template <int VG>
-__global__ __launch_bounds__(256) void spin(float* out, unsigned long long ticks) {
+__global__ __launch_bounds__(1024) void spin(float* out, unsigned long long ticks) {
     extern __shared__ char smem[];
     float keep[VG];                       // VG live VGPRs
 #pragma unroll
@@ -24,24 +24,25 @@ __global__ __launch_bounds__(256) void spin(float* out, unsigned long long ticks
 }
 
 template <int VG>
-static void run(int cus, float* d, int lds) {
+static void run(int cus, float* d, int lds, int threads = 256) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&spin<VG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     int nb = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spin<VG>, 256, lds);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spin<VG>, threads, lds);
     hipFuncAttributes fa;
     hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&spin<VG>));
-    printf("256 threads, %3d VGPRs, %6d B LDS: runtime says %d workgroups / CU;  launch time in spin periods for N per CU:", fa.numRegs,
-           lds, nb);
+    printf("%4d threads, %3d VGPRs, %6d B LDS: runtime says %2d workgroups / CU;  launch time in spin periods for N per CU:",
+           threads, fa.numRegs, lds, nb);
     const unsigned long long ticks = 400000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     float base = 0.f;
-    for (int n = 1; n <= 8; ++n) {
-        hipLaunchKernelGGL(spin<VG>, dim3(cus * n), dim3(256), lds, 0, d, ticks);
+    for (int n : {1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 24, 32, 33}) {
+        if (threads >= 256 && n > 9) break;
+        hipLaunchKernelGGL(spin<VG>, dim3(cus * n), dim3(threads), lds, 0, d, ticks);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(spin<VG>, dim3(cus * n), dim3(256), lds, 0, d, ticks);
+        hipLaunchKernelGGL(spin<VG>, dim3(cus * n), dim3(threads), lds, 0, d, ticks);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
@@ -57,6 +58,10 @@ int main() {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     float* d;
     hipMalloc(&d, 4096);
+    for (int threads : {64, 128, 512, 1024}) run<32>(cus, d, 0, threads);
+    run<100>(cus, d, 0, 64);
+    run<56>(cus, d, 0, 256);
+    run<80>(cus, d, 0, 256);
     for (int lds : {0, 16384, 32768, 49152, 65536}) {
         run<32>(cus, d, lds);
         run<100>(cus, d, lds);
