@@ -4,7 +4,7 @@
 
 #include "common.h"
 
-// No implicit FMA contraction in this file: hipcc's default (-ffp-contract=fast) fused the two rows of norm2_kernel
+// No implicit FMA contraction in this file: hipcc's default (-ffp-contract=fast) fused the rows a wave handles
 // differently — a row's LayerNorm then depended (by one bf16 ulp, in a handful of elements per million) on whether it was
 // the first or the second row of its wave, i.e. on the position of its sample in the batch (found with two identical
 // samples in one batch, tools/debug_vit_bisect.py). Every fused multiply-add below is an explicit __fmaf_rn, written
@@ -115,85 +115,99 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
     }
 }
 
-// Two rows per wave, register-cached (D <= 512*NC): both rows' loads and the weight / bias vectors (shared by the two
-// rows) are issued up front, so a wave has twice the bytes in flight and the gamma/beta fetch is off the critical
-// path between the statistics and the stores.
-template <typename T, bool RMS, int NC>
-__global__ __launch_bounds__(256) void norm2_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ w,
-                                                    const T* __restrict__ b, int M, int D, int64_t ldx, int64_t ldy,
-                                                    float eps) {
+// R rows per wave, cached RAW (bf16, 4 VGPRs per 8 elements) and unpacked where they are used: a CU of this part holds 16
+// waves (profiles/r2_occupancy_probe.txt), so the bytes in flight that cover HBM latency have to come from inside the
+// wave — 8 x 16 B per lane here (R = 4 rows of D <= 1024, R = 2 of D <= 2048) against 4 with fp32-cached rows. Same
+// arithmetic, in the same order, as norm_kernel: a row's result does not depend on its place in the wave.
+__device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
+
+template <bool RMS, int NC, int R>
+__global__ __launch_bounds__(256) void normr_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, int M,
+                                                    int D, int64_t ldx, int64_t ldy, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
-    const bool two = row0 + 1 < M;
-    const T* xr[2] = {x + (int64_t)row0 * ldx, x + (int64_t)(two ? row0 + 1 : row0) * ldx};
-    float v[2][NC][8], ww[NC][8], bb[NC][8];
-    float s[2] = {0.f, 0.f};
+    uint4 raw[R][NC], wr[NC], br[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int i = c * 512 + lane * 8;
         const bool in = i < D;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (in) ld8(xr[r] + i, v[r][c]);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[r][c][e] = 0.f;
-            }
-        }
-        if (in) {
-            ld8(w + i, ww[c]);
-            if (!RMS) ld8(b + i, bb[c]);
+        for (int r = 0; r < R; ++r) {
+            const int rr = min(row0 + r, M - 1);
+            raw[r][c] = in ? *reinterpret_cast<const uint4*>(x + (int64_t)rr * ldx + i) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[r] = RMS ? __fmaf_rn(v[r][c][e], v[r][c][e], s[r]) : s[r] + v[r][c][e];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s[0] += __shfl_xor(s[0], o, 64);
-        s[1] += __shfl_xor(s[1], o, 64);
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 512 + lane * 8;
+        wr[c] = i < D ? *reinterpret_cast<const uint4*>(w + i) : make_uint4(0u, 0u, 0u, 0u);
+        if (!RMS) br[c] = i < D ? *reinterpret_cast<const uint4*>(b + i) : make_uint4(0u, 0u, 0u, 0u);
     }
-    float mean[2] = {0.f, 0.f}, rstd[2];
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float v[8];
+            unpack8(raw[r][c], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[r] = RMS ? __fmaf_rn(v[e], v[e], s[r]) : s[r] + v[e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    float mean[R], rstd[R];
     if (RMS) {
-        rstd[0] = rsqrtf(s[0] / (float)D + eps);
-        rstd[1] = rsqrtf(s[1] / (float)D + eps);
-    } else {
-        float q[2] = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) { mean[r] = 0.f; rstd[r] = rsqrtf(s[r] / (float)D + eps); }
+    } else {
+        float q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             mean[r] = s[r] / (float)D;
+            q[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (c * 512 + lane * 8 < D) {
+                    float v[8];
+                    unpack8(raw[r][c], v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[r][c][e] - mean[r]; q[r] = __fmaf_rn(d, d, q[r]); }
+                    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean[r]; q[r] = __fmaf_rn(d, d, q[r]); }
                 }
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            q[0] += __shfl_xor(q[0], o, 64);
-            q[1] += __shfl_xor(q[1], o, 64);
-        }
-        rstd[0] = rsqrtf(q[0] / (float)D + eps);
-        rstd[1] = rsqrtf(q[1] / (float)D + eps);
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(q[r] / (float)D + eps);
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (r == 1 && !two) break;
-        T* yr = y + (int64_t)(row0 + r) * ldy;
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= M) break;
+        bf16_t* yr = y + (int64_t)(row0 + r) * ldy;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int i = c * 512 + lane * 8;
             if (i >= D) continue;
-            float o[8];
+            float v[8], ww[8], bb[8], o[8];
+            unpack8(raw[r][c], v);
+            unpack8(wr[c], ww);
+            if (!RMS) unpack8(br[c], bb);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                o[e] = RMS ? rms_out<T>(v[r][c][e], rstd[r], ww[c][e]) : ln_out(v[r][c][e], mean[r], rstd[r], ww[c][e], bb[c][e]);
+                o[e] = RMS ? rms_out<bf16_t>(v[e], rstd[r], ww[e]) : ln_out(v[e], mean[r], rstd[r], ww[e], bb[e]);
             st8(yr + i, o);
         }
     }
@@ -214,13 +228,13 @@ static int launch_norm(int dtype, const void* x, void* y, const void* w, const v
     hipLaunchKernelGGL((norm_kernel<TT, RMS, C_>), grid, block, 0, s, (const TT*)x, (TT*)y, (const TT*)w, (const TT*)b, M, \
                        D, ldx, ldy, eps)
     // bf16 rows that fit 2 register chunks and enough rows to fill the chip: two rows per wave (ViT LN 3.8 -> 4.5 TB/s)
-    if (dtype == GAR_BF16 && D <= 1024 && M >= 4096) {     // D = 2048 needs 152 VGPRs and gets slower
-        dim3 grid2((M + 7) / 8);
-#define LAUNCH_NORM2(C_)                                                                                       \
-    hipLaunchKernelGGL((norm2_kernel<bf16_t, RMS, C_>), grid2, block, 0, s, (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)w, \
-                       (const bf16_t*)b, M, D, ldx, ldy, eps)
-        LAUNCH_NORM2(2);
-#undef LAUNCH_NORM2
+    // bf16 rows that fit the register cache and enough rows to fill the chip (ViT LN 5.2 -> 5.9 TB/s, RMSNorm 5.6 -> 5.7)
+    if (dtype == GAR_BF16 && D <= 2048 && M >= 4096) {
+#define LAUNCH_NORMR(C_, R_)                                                                                     \
+    hipLaunchKernelGGL((normr_kernel<RMS, C_, R_>), dim3((M + 4 * R_ - 1) / (4 * R_)), block, 0, s, (const bf16_t*)x, \
+                       (bf16_t*)y, (const bf16_t*)w, (const bf16_t*)b, M, D, ldx, ldy, eps)
+        if (D <= 1024) LAUNCH_NORMR(2, 4); else LAUNCH_NORMR(4, 2);
+#undef LAUNCH_NORMR
         GAR_CHECK_LAUNCH();
         return GAR_OK;
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Micro-benchmark of LayerNorm / RMSNorm at the benchmark's shapes (HIP events). GAR_NORM2=0: one row per wave."""
+"""Micro-benchmark of LayerNorm / RMSNorm at the benchmark's shapes (HIP events)."""
 import os
 import sys
 
