@@ -77,12 +77,15 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
             for (int i = 0; i < 2; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(wreg + t * 2048 + i * 1024), 16,
                                                          voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, 0);
+#ifndef SK_NOX   /* -DSK_NOX: diagnostic build that never stages the activation tiles (wrong results): what the weight
+                    stream alone costs (tools/build_variant.sh, profiles/r2_decode_gemm_experiment.txt) */
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_AS(wreg + (NT + mt) * 2048 + i * 1024), 16,
                                                          voffX[i] + (int)((unsigned)(mt * 16) * rbX + k0b), 0, 0, 0);
+#endif
     };
     const int foff0 = frow * 128 + (((2 * fq) ^ ((frow >> 1) & 7)) << 4);
     const int foff1 = frow * 128 + (((2 * fq + 1) ^ ((frow >> 1) & 7)) << 4);
