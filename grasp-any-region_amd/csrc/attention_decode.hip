@@ -49,7 +49,8 @@ template <int HD>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ Vt, float* __restrict__ part,
                                                                int Hq, int Hkv, int kv_stride,
-                                                               const int32_t* __restrict__ kv_len_dev) {
+                                                               const int32_t* __restrict__ kv_len_dev,
+                                                               bf16_t* __restrict__ O_direct) {
     constexpr int NKD = HD / 16, NDB = HD / 32;
     __shared__ float red[4][8][HD + 2];           // per wave: O[g][d], m, l   (g < G <= 8)
     const int kv_len = kv_len_dev[0];
@@ -176,6 +177,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel
             acc += sc * red[w][g][d];
             l += sc * red[w][g][HD + 1];
         }
+        if (O_direct) {      // a single split: this IS the result (what decode_combine_kernel computes for nsplit = 1)
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            O_direct[((int64_t)b * Hq + kvh * G + g) * HD + d] = f2bf(acc * inv);
+            continue;
+        }
         float* pp = part + ((((int64_t)b * Hkv + kvh) * nsplit + split) * G + g) * (HD + 2);
         pp[d] = acc;
         if (d == 0) { pp[HD] = m; pp[HD + 1] = l; }
@@ -194,7 +200,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel
 __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt, float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
-                                                                 const int32_t* __restrict__ kv_len_dev) {
+                                                                 const int32_t* __restrict__ kv_len_dev,
+                                                                 bf16_t* __restrict__ O_direct) {
     constexpr int HD = 64, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | Vt 8 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 16384);
@@ -364,6 +371,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
             acc += sc * red[w][g][d];
             l += sc * red[w][g][HD + 1];
         }
+        if (O_direct) {      // a single split: this IS the result (what decode_combine_kernel computes for nsplit = 1)
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            O_direct[((int64_t)b * Hq + kvh * G + g) * HD + d] = f2bf(acc * inv);
+            continue;
+        }
         float* pp = part + ((((int64_t)b * Hkv + kvh) * nsplit + split) * G + g) * (HD + 2);
         pp[d] = acc;
         if (d == 0) { pp[HD] = m; pp[HD + 1] = l; }
@@ -415,6 +427,8 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(max_splits, Hkv, B);
+    // one split per (sequence, kv head): the attention kernel normalises and writes O itself, no combine launch
+    bf16_t* direct = max_splits == 1 ? (bf16_t*)O : nullptr;
     if (hd == 64 && (int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {      // DMA-staged kernel; else per-lane fragment loads
         constexpr int lds = 4 * 16384 + 4 * 8 * (64 + 2) * 4;
         static bool attr_set = false;
@@ -424,19 +438,22 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
             attr_set = true;
         }
         hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev);
-        hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace, (bf16_t*)O, Hq,
-                           Hkv, max_splits);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+        if (!direct)
+            hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
+                               (bf16_t*)O, Hq, Hkv, max_splits);
     } else if (hd == 64) {
         hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev);
-        hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace, (bf16_t*)O, Hq,
-                           Hkv, max_splits);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+        if (!direct)
+            hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
+                               (bf16_t*)O, Hq, Hkv, max_splits);
     } else {
         hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev);
-        hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace, (bf16_t*)O,
-                           Hq, Hkv, max_splits);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+        if (!direct)
+            hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
+                               (bf16_t*)O, Hq, Hkv, max_splits);
     }
     GAR_CHECK_LAUNCH();
     return GAR_OK;
