@@ -332,6 +332,11 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
     GAR_CHECK_ARG((p.lda * esz) % 16 == 0 && (p.ldw * esz) % 16 == 0, "gar_gemm: lda/ldw rows must be 16-byte aligned");
     GAR_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "gar_gemm: A/W must be 16-byte aligned");
     const int e = p.epilogue;
+    if (p.split_k > 1)
+        GAR_CHECK_ARG(dtype == GAR_BF16 && p.M <= 64 && e == GAR_EPI_NONE && !p.norm_w && p.partial && p.split_k <= 8 &&
+                          p.K % (64 * p.split_k) == 0 && p.N % 4 == 0,
+                      "gar_gemm: split_k=%d is built for bf16 decode GEMMs (M <= 64, GAR_EPI_NONE, K %% (64 split_k) == 0)",
+                      p.split_k);
     if (e == GAR_EPI_BIAS || e == GAR_EPI_BIAS_GELU || e == GAR_EPI_BIAS_SCALE_RES)
         GAR_CHECK_ARG(p.bias != nullptr && p.N % 4 == 0, "gar_gemm: bias epilogue needs bias and N%%4==0");
     if (e == GAR_EPI_BIAS_SCALE_RES) GAR_CHECK_ARG(p.gamma && p.residual, "gar_gemm: SCALE_RES needs gamma+residual");

@@ -31,9 +31,14 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
     const bf16_t* W = (const bf16_t*)p.W;
     const bf16_t* X = (const bf16_t*)p.A;
     const bf16_t* Gw = (const bf16_t*)p.norm_w;
-    const int ksteps = p.K / 64;
+    // split-K (p.split_k > 1, GAR_EPI_NONE only): blockIdx.y owns one of split_k equal K slices and writes its fp32
+    // product to p.partial [split_k][M][N]; gar_splitk_residual_rmsnorm sums the slices (no atomics, no fences: the
+    // reduction is the next launch)
+    const int nsplit = p.split_k > 1 ? p.split_k : 1;
+    const int ksteps = p.K / 64 / nsplit;
+    const int kbase = (int)blockIdx.y * ksteps;
     const int per = (ksteps + nw - 1) / nw;
-    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const int ks0 = kbase + wave * per, ks1 = min(kbase + ksteps, ks0 + per);
     const bf16_t* xp[MT];
     bool xv[MT];
 #pragma unroll
@@ -229,6 +234,15 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
                 for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
         }
         if (m >= p.M) continue;
+        if (EPI == GAR_EPI_NONE && nsplit > 1) {
+            float* part = reinterpret_cast<float*>(p.partial) + ((int64_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + fq * 4;
+                if (n < p.N) *reinterpret_cast<f32x4*>(part + n) = f32x4{v[t][0], v[t][1], v[t][2], v[t][3]};
+            }
+            continue;
+        }
         if (EPI == GAR_EPI_SWIGLU) {          // weight tiles come in (gate16, up16) pairs
 #pragma unroll
             for (int q = 0; q < NT / 2; ++q) {
@@ -250,7 +264,8 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
 template <int EPI, int MT, int NT>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     const int nb = (p.N + 16 * NT - 1) / (16 * NT);
-    const int ksteps = p.K / 64;
+    const int nsplit = (EPI == GAR_EPI_NONE && p.split_k > 1) ? p.split_k : 1;
+    const int ksteps = p.K / 64 / nsplit;
     // buffer descriptors address W / x with 32-bit byte offsets (larger operands take the per-lane fragment loads)
     const bool staged = ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) &&
                         ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
@@ -279,10 +294,10 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     int nw = 4;
     // 4-tile blocks and the fused-norm 4-row-tile blocks are built for <= 512 threads (256 VGPRs)
     const int max_nw = (NT >= 4 || (p.norm_w && MT >= 4)) ? 8 : 16;
-    while (nw < max_nw && nb * nw < 2048 && ksteps / (nw * 2) >= 2 && lds_for(nw * 2) <= MAXLDS) nw *= 2;
+    while (nw < max_nw && nb * nsplit * nw < 2048 && ksteps / (nw * 2) >= 2 && lds_for(nw * 2) <= MAXLDS) nw *= 2;
     const int lds = lds_for(nw);
 #define LAUNCH_SK(NORM_, ST_) \
-    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_>), dim3(nb), dim3(nw * 64), lds, s, p)
+    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_>), dim3(nb, nsplit), dim3(nw * 64), lds, s, p)
     if constexpr (NT <= 2) {
         if (p.norm_w) {
             if (staged) LAUNCH_SK(true, true); else LAUNCH_SK(true, false);

@@ -248,6 +248,103 @@ static int launch_norm(int dtype, const void* x, void* y, const void* w, const v
     return GAR_OK;
 }
 
+// Reduction of a split-K decode GEMM (gemm_skinny.hip, p.split_k > 1) + residual add + the RMSNorm that follows it in a
+// Llama layer, one wave per row (M <= 64). The residual stream is rounded to bf16 exactly where GAR_EPI_RES rounds it, and
+// the norm reads the ROUNDED row with norm_kernel's arithmetic (same chunk / lane / element order), so this launch gives
+// what `gemm(EPI_RES)` + `rmsnorm` give up to the fp32 summation order of the K slices.
+template <int NC, int SMAX>
+__global__ __launch_bounds__(256) void splitk_res_rms_kernel(const float* __restrict__ part, int S, bf16_t* __restrict__ h,
+                                                             const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int M,
+                                                             int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    bf16_t* hr = h + (int64_t)row * D;
+    // every load of the row (S slices x NC chunks + the residual + the weight) is issued before the first add: the launch
+    // is 64 waves on an otherwise idle chip, i.e. pure latency
+    float4 pa[NC][SMAX][2];
+    uint4 hraw[NC], wraw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 512 + lane * 8;
+        const bool in = i < D;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            const bool on = in && s < S;
+            const float4* src = reinterpret_cast<const float4*>(part + ((int64_t)(on ? s : 0) * M + row) * D + (in ? i : 0));
+            pa[c][s][0] = on ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa[c][s][1] = on ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        hraw[c] = in ? *reinterpret_cast<const uint4*>(hr + i) : make_uint4(0u, 0u, 0u, 0u);
+        wraw[c] = (in && y) ? *reinterpret_cast<const uint4*>(w + i) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float v[NC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 512 + lane * 8;
+        float acc[8], r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            if (s < S) {                                   // slices in order; a skipped slice adds nothing (not even +0)
+                const float t[8] = {pa[c][s][0].x, pa[c][s][0].y, pa[c][s][0].z, pa[c][s][0].w,
+                                    pa[c][s][1].x, pa[c][s][1].y, pa[c][s][1].z, pa[c][s][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = acc[e] + t[e];
+            }
+        }
+        unpack8(hraw[c], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = i < D ? bf2f(f2bf(r[e] + acc[e])) : 0.f;
+        if (i < D) st8(hr + i, v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = __fmaf_rn(v[c][e], v[c][e], ss);
+    }
+    if (!y) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    bf16_t* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = c * 512 + lane * 8;
+        if (i >= D) continue;
+        float ww[8], o[8];
+        unpack8(wraw[c], ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rms_out<bf16_t>(v[c][e], rstd, ww[e]);
+        st8(yr + i, o);
+    }
+}
+
+extern "C" int gar_splitk_residual_rmsnorm(int dtype, const float* partial, int split_k, void* h, const void* w, void* y,
+                                           int M, int D, float eps, gar_stream_t stream) {
+    GAR_CHECK_ARG(dtype == GAR_BF16, "splitk_residual_rmsnorm: bf16 only");
+    GAR_CHECK_ARG(partial && h && (w || !y), "splitk_residual_rmsnorm: null pointer");
+    GAR_CHECK_ARG(split_k >= 1 && split_k <= (D <= 2048 ? 8 : 4) && M > 0 && M <= 64 && D > 0 && D % 8 == 0 && D <= 4096,
+                  "splitk_residual_rmsnorm: bad shape (split_k %d, M %d, D %d)", split_k, M, D);
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_SKR(C_)                                                                                              \
+    do {                                                                                                            \
+        if (split_k <= 4)                                                                                           \
+            hipLaunchKernelGGL((splitk_res_rms_kernel<C_, 4>), grid, block, 0, s, partial, split_k, (bf16_t*)h,     \
+                               (const bf16_t*)w, (bf16_t*)y, M, D, eps);                                            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((splitk_res_rms_kernel<C_, 8>), grid, block, 0, s, partial, split_k, (bf16_t*)h,     \
+                               (const bf16_t*)w, (bf16_t*)y, M, D, eps);                                            \
+    } while (0)
+    if (D <= 1024) LAUNCH_SKR(2);
+    else if (D <= 2048) LAUNCH_SKR(4);
+    else hipLaunchKernelGGL((splitk_res_rms_kernel<8, 4>), grid, block, 0, s, partial, split_k, (bf16_t*)h,
+                            (const bf16_t*)w, (bf16_t*)y, M, D, eps);
+#undef LAUNCH_SKR
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
 extern "C" int gar_layernorm(int dtype, const void* x, void* y, const void* w, const void* b, int M, int D, int64_t ldx,
                              int64_t ldy, float eps, gar_stream_t stream) {
     return launch_norm<false>(dtype, x, y, w, b, M, D, ldx, ldy, eps, stream);

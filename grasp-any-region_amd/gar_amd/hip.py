@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
 GAR_F32, GAR_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GarError(RuntimeError):
@@ -29,7 +29,8 @@ class GemmParams(C.Structure):
                 ("token_offset", C.c_int32), ("norm_eps", C.c_float), ("norm_w", C.c_void_p),
                 ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_sin", C.c_void_p), ("qkv_cos", C.c_void_p),
                 ("qkv_heads", C.c_int32), ("qkv_head_dim", C.c_int32), ("qkv_tokens", C.c_int32),
-                ("qkv_tokens_pad", C.c_int32), ("qkv_prefix", C.c_int32), ("qkv_q_scale", C.c_float)]
+                ("qkv_tokens_pad", C.c_int32), ("qkv_prefix", C.c_int32), ("qkv_q_scale", C.c_float),
+                ("split_k", C.c_int32), ("partial", C.c_void_p)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -42,6 +43,7 @@ SIGNATURES = {
     "gar_cls_pos_fill": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "gar_layernorm": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
     "gar_rmsnorm": ([_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
+    "gar_splitk_residual_rmsnorm": ([_i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "gar_vit_v_transpose": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp], _i),

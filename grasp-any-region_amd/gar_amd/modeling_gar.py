@@ -251,6 +251,8 @@ class GARModel:
     # the KV-cache states are kept in an LRU of MAX_LLM_STATES entries (their graphs go with them).
     _CAPACITY_FAMILIES = ("vit", "emb", "prefill")
     MAX_LLM_STATES = 2
+    DOWN_SPLIT_K = 2          # K slices of the decode `down` GEMM at more than FUSE_NORM_MAX_BATCH rows (1 = off; 2 and 4
+                              # measure the same 21.6-21.9 us per layer against 28.6 unsplit, tools/bench_skinny.py)
 
     def _buf(self, key: tuple, name: str, shape, dtype=None, zero=False):
         dtype = dtype or self.dtype
@@ -494,8 +496,9 @@ class GARModel:
             ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
 
-    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None):
-        """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed)."""
+    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None):
+        """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed). ``normed``: the
+        rows after the final norm, when the caller's last launch produced them already (split-K decode path)."""
         cur = st["cur"] if cur is None else cur
         t = self.config.mllm_config.text_config
         C_l, V = t.hidden_size, t.vocab_size
@@ -504,7 +507,9 @@ class GARModel:
         Vld = _round_up(V, 64)
         logits = self._buf(key, "logits", (B, Vld))
         ws = self._buf(key, "amws", (ops.argmax_workspace(B, V),), torch.uint8)
-        if B <= 16:         # RMSNorm folded into the GEMV prologue; for more rows one tiny norm launch is cheaper
+        if normed is not None:
+            ops.gemm(normed, self.lm_head, logits)
+        elif B <= 16:       # RMSNorm folded into the GEMV prologue; for more rows one tiny norm launch is cheaper
             ops.gemm(last_rows, self.lm_head, logits, norm_w=self.final_norm, norm_eps=t.rms_norm_eps)
         else:
             ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
@@ -531,11 +536,18 @@ class GARModel:
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
         fuse = B <= self.FUSE_NORM_MAX_BATCH     # every block redoes x*g in the prologue: only pays for <= 16 rows
+        # `down` (K = intermediate size, only hidden/16 weight tiles) streams from DOWN_SPLIT_K x the workgroups as K slices
+        # whose fp32 products are reduced — with the residual add and the next RMSNorm — by the launch that follows anyway
+        split = self.DOWN_SPLIT_K if (not fuse and self.dtype == torch.bfloat16 and F % (64 * self.DOWN_SPLIT_K) == 0
+                                      and C_l <= 4096) else 1
+        partial = self._buf(key, "down_partial", (split, B, C_l), torch.float32) if split > 1 else None
+        normed = None
         for li, ly in enumerate(self.layers):
             if fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
             else:
-                ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+                if split == 1 or li == 0:
+                    ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["qkv"], qkv)
             ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale)
             ops.attention_decode(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws)
@@ -545,8 +557,14 @@ class GARModel:
             else:
                 ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
-            ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
-        logits = self._head(h, B, out_tokens, st)
+            if split > 1:
+                ops.gemm(ff, ly["down"], None, partial=partial)
+                nxt = self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.final_norm
+                ops.splitk_residual_rmsnorm(partial, h, nxt, t.rms_norm_eps, out=xn)    # h += down; xn = norm(h)
+                normed = xn
+            else:
+                ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
+        logits = self._head(h, B, out_tokens, st, normed=normed)
         ops.counter_add(st["counters"][0:3], 1)
         return logits
 

@@ -37,13 +37,20 @@ def _chk(t: torch.Tensor, name: str):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, bias=None, residual=None,
          gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0, norm_w=None,
-         norm_eps: float = 0.0):
-    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views."""
-    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
-    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(-1) == 1
+         norm_eps: float = 0.0, partial: Optional[torch.Tensor] = None):
+    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views.
+    ``partial`` fp32 [split_k, M, N] (decode GEMMs, EPI_NONE): the K range is cut into split_k slices whose products go
+    there instead of ``out`` (pass ``out=None``); ``splitk_residual_rmsnorm`` reduces them."""
+    assert a.dim() == 2
     M, K = a.shape
-    N = w.shape[0]
     p = GemmParams()
+    assert w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1, (a.shape, w.shape)
+    N = w.shape[0]
+    if partial is not None:
+        assert out is None and partial.dtype == torch.float32 and partial.is_contiguous() and partial.shape[1:] == (M, N)
+        p.split_k, p.partial = partial.shape[0], ptr(partial)
+        out = partial
+    assert a.stride(1) == 1 and out.stride(-1) == 1
     p.A, p.lda = ptr(a), a.stride(0)
     p.W, p.ldw = ptr(w), w.stride(0)
     p.C = ptr(out)
@@ -69,6 +76,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         return out
     check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
     return out
+
+
+def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[torch.Tensor], eps: float,
+                            out: Optional[torch.Tensor] = None):
+    """h += sum over the K slices of ``partial`` [split_k, M, D] (one bf16 rounding, like EPI_RES); ``out`` = RMSNorm(h; w)
+    when given (the next layer's input_layernorm / the final norm)."""
+    S, M, D = partial.shape
+    assert h.is_contiguous() and h.shape == (M, D) and (out is None or (out.is_contiguous() and out.shape == (M, D)))
+    check(lib().gar_splitk_residual_rmsnorm(dtype_code(h.dtype), ptr(partial), S, ptr(h), ptr(w), ptr(out), M, D, eps,
+                                            stream()), "gar_splitk_residual_rmsnorm")
+    return h
 
 
 def patch_im2col(pixel: torch.Tensor, mask: Optional[torch.Tensor], out: torch.Tensor, patch: int, prompt_numbers: int):

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 3
+#define GAR_ABI_VERSION 4
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -81,6 +81,11 @@ typedef struct gar_gemm_params {
                                                   /* the tables repeat each value for both elements of a rotated pair (timm) */
     int32_t qkv_heads, qkv_head_dim, qkv_tokens, qkv_tokens_pad, qkv_prefix;
     float qkv_q_scale;
+    /* Split-K for the decode GEMMs (bf16, M <= 64, GAR_EPI_NONE, no norm_w): with split_k > 1 the K range is cut into
+     * split_k equal slices (K % (64 split_k) == 0, N % 4 == 0), every slice's fp32 product goes to `partial`
+     * [split_k][M][N] (C is not written) and gar_splitk_residual_rmsnorm — the launch that follows anyway — sums them.
+     * No atomics and no fences: a narrow output (Llama `down`: 128 weight tiles) then streams from 4x the workgroups. */
+    int32_t split_k; float* partial;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -106,6 +111,13 @@ int gar_layernorm(int dtype, const void* x, void* y, const void* w, const void* 
                   int64_t ldy, float eps, gar_stream_t stream);
 int gar_rmsnorm(int dtype, const void* x, void* y, const void* w, int M, int D, int64_t ldx, int64_t ldy, float eps,
                 gar_stream_t stream);
+/* The reduction of a split-K decode GEMM fused with what follows it in a Llama layer (HF LlamaDecoderLayer:
+ * hidden = residual + mlp(...); next layer's input_layernorm — modeling_gar.py:418-426 -> transformers LlamaModel):
+ *   h[m, :] = round(h[m, :] + sum_s partial[s][m][:])   (slices added in order s = 0, 1, ...; one rounding, like GAR_EPI_RES)
+ *   y[m, :] = LlamaRMSNorm(h[m, :]; w)                  (y == NULL: residual update only)
+ * bf16, M <= 64 rows, D % 8 == 0, D <= 4096, split_k <= 8 (<= 4 when D > 2048); h and y contiguous [M, D]. */
+int gar_splitk_residual_rmsnorm(int dtype, const float* partial, int split_k, void* h, const void* w, void* y, int M,
+                                int D, float eps, gar_stream_t stream);
 
 /* timm AttentionRope pre-attention step on the fused qkv output [T*N, 3*H*hd]: interleaved-pair 2-D RoPE on q,k
  * for tokens >= npt (tables sin/cos [N-npt, hd] f32), softmax scale*log2(e) folded into q, and re-layout to

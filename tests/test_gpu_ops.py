@@ -636,6 +636,53 @@ def test_skinny_gemm_batched_rows_bf16(dev, M):
     close(o1[0], out[M - 1].float(), dt)
 
 
+@pytest.mark.parametrize("M", [17, 40, 64])
+@pytest.mark.parametrize("S", [2, 4, 8])
+def test_decode_gemm_split_k_and_fused_reduce(dev, M, S):
+    """Llama `down` at decode time: K slices of the GEMM written as fp32 partials (gar_gemm split_k) and reduced, together
+    with the residual add and the RMSNorm that follows, by gar_splitk_residual_rmsnorm — against fp64, and against the
+    unfused pair gemm(EPI_RES) + rmsnorm it replaces (same roundings; only the fp32 summation order of the slices
+    differs)."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    K, N = 8192, 2048
+    x = q(rnd(M, K, seed=80, scale=1.5), dt)
+    w = q(rnd(N, K, seed=81, scale=K ** -0.5), dt)
+    h0 = q(rnd(M, N, seed=82), dt)
+    g = q(1 + 0.1 * rnd(N, seed=83), dt)
+    xg, wg, gg = x.to(dev, dt), w.to(dev, dt), g.to(dev, dt)
+    partial = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemm(xg, wg, None, partial=partial)
+    prod = x.double() @ w.double().T
+    close(partial.sum(0), prod, torch.float32, extra=50.0)            # fp32 accumulation of bf16 products over K = 8192
+    for s_ in range(S):                                               # every slice is its own K range
+        ks = K // S
+        close(partial[s_], x[:, s_ * ks:(s_ + 1) * ks].double() @ w[:, s_ * ks:(s_ + 1) * ks].double().T, torch.float32,
+              extra=50.0)
+    h = h0.to(dev, dt).clone()
+    y = torch.empty(M, N, dtype=dt, device=dev)
+    ops.splitk_residual_rmsnorm(partial, h, gg, 1e-5, out=y)
+    href = h0.double() + prod
+    close(h, href, dt)
+    hr = h.float().cpu().double()                                     # the norm reads the rounded residual stream
+    close(y, hr * torch.rsqrt(hr.pow(2).mean(-1, keepdim=True) + 1e-5) * g.double(), dt, extra=2.0)
+    # the unfused pair
+    h1 = h0.to(dev, dt).clone()
+    ops.gemm(xg, wg, h1, hip.EPI_RES, residual=h1)
+    y1 = torch.empty(M, N, dtype=dt, device=dev)
+    ops.rmsnorm(h1, gg, 1e-5, out=y1)
+    ulp = (h.float() - h1.float()).abs() / h1.float().abs().clamp_min(1e-3)
+    assert float(ulp.max()) <= 2 ** -7 and float((h != h1).float().mean()) < 0.02      # rare 1-ulp flips only
+    same = (h == h1).all(-1)
+    assert bool(same.any()) and torch.equal(y[same], y1[same])       # identical rows in -> identical rows out
+    # residual update only (no norm output)
+    h2 = h0.to(dev, dt).clone()
+    ops.splitk_residual_rmsnorm(partial, h2, None, 1e-5, out=None)
+    assert torch.equal(h2, h)
+    with pytest.raises(hip.GarError):
+        ops.gemm(xg, wg, None, hip.EPI_RES, residual=h1, partial=partial)
+
+
 def test_abi_errors_are_reported_not_thrown(dev):
     from gar_amd import hip, ops
     a = torch.zeros(4, 60, device=dev)

@@ -48,6 +48,45 @@ def main():
             tot += per_step
             print(f"M={M:3d} {name:8s} N={N:6d} K={K:5d}  {us:8.1f} us  {nb / us / 1e6:7.2f} TB/s", flush=True)
         print(f"M={M:3d} GEMMs of one decode step (16 layers + head): {tot / 1e3:.3f} ms", flush=True)
+        if M > 16:      # `down` as split-K partials + the fused reduce / residual / RMSNorm launch, against down(EPI_RES) + rmsnorm
+            N, K = 2048, 8192
+            ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(L)]
+            a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+            h = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+            y = torch.empty_like(h)
+            g = torch.ones(N, device=dev, dtype=torch.bfloat16)
+            for S in (1, 2, 4, 8):
+                part = torch.empty(S, M, N, device=dev, dtype=torch.float32)
+
+                def run(what):
+                    for w in ws:
+                        if S == 1:
+                            if what != "reduce":
+                                ops.gemm(a, w, h, hip.EPI_RES, residual=h)
+                            if what != "gemm":
+                                ops.rmsnorm(h, g, 1e-5, out=y)
+                        else:
+                            if what != "reduce":
+                                ops.gemm(a, w, None, partial=part)
+                            if what != "gemm":
+                                ops.splitk_residual_rmsnorm(part, h, g, 1e-5, out=y)
+                res = {}
+                for what in ("both", "gemm", "reduce"):
+                    run(what)
+                    torch.cuda.synchronize()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        run(what)
+                    gr.replay()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        gr.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res[what] = e0.elapsed_time(e1) / 5 / len(ws) * 1e3
+                print(f"M={M:3d} down + residual + next RMSNorm, split_k={S}: {res['both']:6.1f} us per layer "
+                      f"(GEMM alone {res['gemm']:5.1f}, reduce / norm launch alone {res['reduce']:5.1f})", flush=True)
 
 
 if __name__ == "__main__":
