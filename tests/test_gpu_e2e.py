@@ -255,6 +255,46 @@ def test_full_size_bf16_properties():
     assert torch.equal(c.sequences[0], c.sequences[1]) and int(c.sequences[0, 0]) == int(a.sequences[0, 0])
 
 
+def test_bf16_decode_above_16_sequences_matches_f32_teacher_forced(tiny):
+    """More than 16 sequences per step take the other decode schedule (separate RMSNorm launches, `down` as split-K slices
+    reduced by gar_splitk_residual_rmsnorm, single-split attention writing its output itself): 20 sequences in bf16,
+    teacher-forced on the f32 HIP run of the same batch — per-step logits within the bf16 tolerance, repeated samples give
+    identical rows, hipGraph replay == eager launches."""
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    ss = [_sample(cfg, proc, i) for i in (3, 4, 6, 7)]
+    assert len({tuple(s["input_ids"].shape) for s in ss}) == 1
+    order = [0, 1, 2, 3, 0] * 4                                   # 20 rows, sample 0 at rows 0, 4, 5, 9, ...
+
+    def batch(dt):
+        return dict(input_ids=torch.cat([ss[i]["input_ids"] for i in order]),
+                    pixel_values=torch.cat([ss[i]["pixel_values"] for i in order]).to(dt),
+                    global_mask_values=torch.cat([ss[i]["global_mask_values"] for i in order]).to(dt),
+                    bboxes=[ss[i]["bboxes"][0] for i in order],
+                    aspect_ratios=torch.cat([ss[i]["aspect_ratios"] for i in order]))
+    n = 6
+    m32, m16 = GARModel(cfg, W, torch.float32), GARModel(cfg, W, torch.bfloat16)
+    r32 = m32.generate(**batch(torch.float32), max_new_tokens=n, return_logits=True)
+    r16 = m16.generate(**batch(torch.bfloat16), max_new_tokens=n, return_logits=True, forced_tokens=r32.sequences)
+    assert m16.DOWN_SPLIT_K > 1 and ("decode", 20) in m16._ws and "down_partial" in m16._ws[("decode", 20)]
+    m16u = GARModel(cfg, W, torch.bfloat16)
+    m16u.DOWN_SPLIT_K = 1                                         # the unsplit schedule: gemm(EPI_RES) + rmsnorm
+    u16 = m16u.generate(**batch(torch.bfloat16), max_new_tokens=n, return_logits=True, forced_tokens=r32.sequences)
+    assert "down_partial" not in m16u._ws[("decode", 20)]
+    for j in range(n):
+        # bf16 vs f32 at a teacher-forced step (the first-token tolerance + what later steps add, as in the full-depth test)
+        assert _rel_l2(r16.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
+        assert _rel_l2(u16.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
+        # split vs unsplit differ by the fp32 summation order of `down` only: an order of magnitude closer to each other
+        assert _rel_l2(r16.logits[:, j], u16.logits[:, j]) < 5e-3, j
+    lg = r16.logits.cpu()
+    for a, b in ((0, 4), (0, 5), (1, 6), (3, 8)):                 # rows of the same sample
+        assert order[a] == order[b] and torch.equal(lg[a], lg[b])
+    eager = m16.generate(**batch(torch.bfloat16), max_new_tokens=n, return_logits=True, forced_tokens=r32.sequences,
+                         use_graph=False)
+    assert torch.equal(eager.logits, r16.logits) and torch.equal(eager.sequences, r16.sequences)
+
+
 def _tiny_8b_like():
     """GAR-8B's structure at tiny sizes: PE-G style ViT (head_dim 96, NO cls token), Llama-3.1-8B style text model
     (head_dim 128, GQA 4:1, untied lm_head)."""
