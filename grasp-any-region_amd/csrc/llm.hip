@@ -24,8 +24,60 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
     const int i8 = (tid % LPT) * 8;
     const int p0 = pos_dev ? pos_dev[0] : pos0;
     const int W = (Hq + 2 * Hkv) * HD;
-    for (int head = 0; head < Hq + 2 * Hkv; ++head) {
-        const bool isq = head < Hq, isk = !isq && head < Hq + Hkv;
+    // rotary heads (q, k): a thread keeps its token and its 8-wide slice for every head, so cos / sin are loaded once per
+    // pass and the rows of RU heads are in flight together (a CU holds 16 waves: the latency cover has to come from here)
+    constexpr int RU = 4;
+    for (int pass = 0; pass < 64 / TPP; ++pass) {
+        const int nl = pass * TPP + tid / LPT;
+        const int s = ch * 64 + nl;
+        float c[8], sv[8];
+        if (s < S) {
+            ld8(cs + (int64_t)(p0 + s) * HALF + i8, c);
+            ld8(sn + (int64_t)(p0 + s) * HALF + i8, sv);
+        }
+        for (int head0 = 0; head0 < Hq + Hkv; head0 += RU) {
+            float x1[RU][8], x2[RU][8];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int head = head0 + u;
+                if (s < S && head < Hq + Hkv) {
+                    const T* row = qkv + ((int64_t)b * S + s) * W + head * HD;
+                    ld8(row + i8, x1[u]);
+                    ld8(row + HALF + i8, x2[u]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x1[u][e] = x2[u][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int head = head0 + u;
+                if (head >= Hq + Hkv) break;
+                const bool isq = head < Hq;
+                if (s < S) {
+                    const float sc = isq ? q_scale : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {   // q*cos + rotate_half(q)*sin
+                        const float o1 = x1[u][e] * c[e] + (-x2[u][e]) * sv[e];
+                        const float o2 = x2[u][e] * c[e] + x1[u][e] * sv[e];
+                        x1[u][e] = o1 * sc;
+                        x2[u][e] = o2 * sc;
+                    }
+                }
+                if (isq && s < Spad) {
+                    T* o = Q + (((int64_t)b * Hq + head) * Spad + s) * HD;
+                    st8(o + i8, x1[u]);
+                    st8(o + HALF + i8, x2[u]);
+                } else if (!isq && s < S) {
+                    T* o = Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0 + s) * HD;
+                    st8(o + i8, x1[u]);
+                    st8(o + HALF + i8, x2[u]);
+                }
+            }
+        }
+    }
+    // v heads: transposed into the cache through LDS
+    for (int head = Hq + Hkv; head < Hq + 2 * Hkv; ++head) {
         for (int pass = 0; pass < 64 / TPP; ++pass) {
             const int nl = pass * TPP + tid / LPT;
             const int s = ch * 64 + nl;
@@ -38,38 +90,13 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x1[e] = x2[e] = 0.f;
             }
-            if (isq || isk) {
-                if (s < S) {
-                    const float* cp = cs + (int64_t)(p0 + s) * HALF + i8;
-                    const float* sp = sn + (int64_t)(p0 + s) * HALF + i8;
-                    const float sc = isq ? q_scale : 1.0f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {   // q*cos + rotate_half(q)*sin
-                        const float c = cp[e], sv = sp[e];
-                        const float o1 = x1[e] * c + (-x2[e]) * sv;
-                        const float o2 = x2[e] * c + x1[e] * sv;
-                        x1[e] = o1 * sc;
-                        x2[e] = o2 * sc;
-                    }
-                }
-                if (isq && s < Spad) {
-                    T* o = Q + (((int64_t)b * Hq + head) * Spad + s) * HD;
-                    st8(o + i8, x1);
-                    st8(o + HALF + i8, x2);
-                } else if (isk && s < S) {
-                    T* o = Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0 + s) * HD;
-                    st8(o + i8, x1);
-                    st8(o + HALF + i8, x2);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    DT<T>::st(&vs[nl * (HD + 2) + i8 + e], x1[e]);
-                    DT<T>::st(&vs[nl * (HD + 2) + HALF + i8 + e], x2[e]);
-                }
+            for (int e = 0; e < 8; ++e) {
+                DT<T>::st(&vs[nl * (HD + 2) + i8 + e], x1[e]);
+                DT<T>::st(&vs[nl * (HD + 2) + HALF + i8 + e], x2[e]);
             }
         }
-        if (!isq && !isk) {
+        {
             __syncthreads();
             const int hv = head - Hq - Hkv;
             T* vbase = Vtc + ((int64_t)b * Hkv + hv) * HD * (int64_t)Smax;
