@@ -297,7 +297,7 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("S", [70, 333])
+@pytest.mark.parametrize("S", [70, 333, 129])
 def test_llm_prefill_then_decode_attention(dev, dt, S):
     """llm_qkv_post (half-split RoPE, GQA, cache append incl. transposed V) + causal prefill attention, then two
     single-token decode steps with the kv length read from device memory."""
