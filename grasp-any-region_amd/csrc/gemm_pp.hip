@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         stage_half(rsW, voffW, rbW, base + 128u * rbW, st + 3 * PHALF, wave);
     };
 
-#ifdef PP_DEPHASE   /* diagnostic build (tools/r2_measure3.sh): workgroups on odd XCDs (PP_DEPHASE = 1) or on odd CU slots of
+#ifdef PP_DEPHASE   /* diagnostic build (tools/runs/r2_measure3.sh): workgroups on odd XCDs (PP_DEPHASE = 1) or on odd CU slots of
                        every XCD (2) start half a tile period late, so that one half of the chip stores while the other
                        half computes */
     if ((PP_DEPHASE == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1)) && total > (int)gridDim.x) {
