@@ -382,6 +382,216 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-staged variant for head_dim 128 (Llama-3.1-8B): a 64-kv tile is 16 KiB of K (256-byte rows) + 16 KiB of Vt per wave.
+// Pulling both into registers before re-arming the region (what the head_dim-64 kernel does) would need 128 VGPRs of
+// fragments on top of the 64 of O, so K and Vt are two phases with their own DMA groups and counted waits:
+//   wait K(t) [vmcnt: the 16 Vt pieces behind it may stay out] -> K fragments -> re-arm K with tile t+4 -> QK^T, softmax
+//   wait Vt(t) [the 16 K pieces just issued may stay out]      -> Vt fragments -> re-arm Vt            -> PV
+// 128 KiB + merge buffer per block: one block (4 waves) per CU, the same 128 KiB of loads in flight per CU.
+__global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                    const bf16_t* __restrict__ Vt, float* __restrict__ part,
+                                                                    int Hq, int Hkv, int kv_stride,
+                                                                    const int32_t* __restrict__ kv_len_dev,
+                                                                    bf16_t* __restrict__ O_direct) {
+    constexpr int HD = 128, NKD = HD / 16, NDB = HD / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | Vt 16 KiB] then red
+    float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 32768);
+    const int kv_len = kv_len_dev[0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int G = Hq / Hkv;
+    const int ntiles = (kv_len + 63) / 64;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const unsigned slab = (unsigned)kv_stride * HD * 2u;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
+    char* ks = smem + wave * 32768;
+    char* vs = ks + 16384;
+    // K piece i = rows 4i .. 4i+3 (256 B each); row r keeps its 16-byte chunk c at position c ^ (r & 15)
+    // Vt piece i = d-rows 8i .. 8i+7 (128 B = 64 kv each); row r keeps chunk c at c ^ ((r >> 1) & 7)
+    int offK[4], offV[2];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int r = lane >> 4;                                    // row inside the piece
+        const int c = (lane & 15) ^ ((q4 * 4 + r) & 15);
+        offK[q4] = r * 256 + (c << 4);
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int sub = lane >> 3;
+        const int c = (lane & 7) ^ ((lane >> 4) | (par << 2));
+        offV[par] = (int)((unsigned)sub * (unsigned)kv_stride * 2u) + (c << 4);
+    }
+    auto stageK = [&](int t) {
+        const unsigned kbase = (unsigned)t * 64u * 256u;        // 64 kv rows of 256 B
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + i * 1024), 16,
+                                                     offK[i & 3] + (int)(kbase + (unsigned)i * 1024u), 0, 0, 0);
+    };
+    auto stageV = [&](int t) {
+        const unsigned vbase = (unsigned)t * 128u;              // 64 kv columns
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + i * 1024), 16,
+                                                     offV[i & 1] + (int)(vbase + (unsigned)i * 8u * (unsigned)kv_stride * 2u),
+                                                     0, 0, 0);
+    };
+    bf16x8 qf[NKD];
+    {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+            qf[kd] = l31 < G ? *reinterpret_cast<const bf16x8*>(qp + kd * 16 + h * 8) : z;
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int koff[2], kkey[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int row = blk * 32 + prow;
+        koff[blk] = row * 256;
+        kkey[blk] = row & 15;
+    }
+
+    int t = t0 + wave;
+    if (t < t1) { stageK(t); stageV(t); }
+    for (; t < t1; t += 4) {
+        const bool more = t + 4 < t1;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K(t) landed; the 16 Vt(t) pieces may still be out
+        f32x16 s[2];
+        {
+            bf16x8 kf[2][NKD];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int kd = 0; kd < NKD; ++kd)
+                    kf[blk][kd] = *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stageK(t + 4);             // re-arm the K half: its fragments are in registers now
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int kd = 0; kd < NKD; ++kd)
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+        }
+        const int kv0 = t * 64;
+        if (kv0 + 64 > kv_len) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
+                    s[blk][r] = kv < kv_len ? s[blk][r] : -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float ps = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                u32x4 w;
+                w[0] = cvt_pk_d(p[tt * 8 + 0], p[tt * 8 + 1]);
+                w[1] = cvt_pk_d(p[tt * 8 + 2], p[tt * 8 + 3]);
+                w[2] = cvt_pk_d(p[tt * 8 + 4], p[tt * 8 + 5]);
+                w[3] = cvt_pk_d(p[tt * 8 + 6], p[tt * 8 + 7]);
+                pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        l_run = l_run * alpha + ps;
+        // Vt(t): everything issued before K(t+4) has to be in; the 16 K pieces just issued may stay out
+        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8 vf[NDB][4];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const int row = d * 32 + l31;
+            const int key = (row >> 1) & 7;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+                vf[d][c4] = *reinterpret_cast<const bf16x8*>(vs + row * 128 + (((c4 * 2 + h) ^ key) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stageV(t + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
+        }
+    }
+    // ---- merge the four waves (LDS), one partial per block — identical to decode_attn_bf16_kernel
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (l31 < G) {
+        float* pp = &red[wave][l31][0];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp[d * 32 + g4 * 8 + h * 4 + e] = o[d][g4 * 4 + e];
+        if (h == 0) { pp[HD] = m_run; pp[HD + 1] = l_tot; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * HD; idx += 256) {
+        const int g = idx / HD, d = idx % HD;
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w][g][HD]);
+        const float m_use = m == -INFINITY ? 0.f : m;
+        float acc = 0.f, l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __builtin_amdgcn_exp2f(red[w][g][HD] - m_use);
+            acc += sc * red[w][g][d];
+            l += sc * red[w][g][HD + 1];
+        }
+        if (O_direct) {      // a single split: this IS the result (what decode_combine_kernel computes for nsplit = 1)
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            O_direct[((int64_t)b * Hq + kvh * G + g) * HD + d] = f2bf(acc * inv);
+            continue;
+        }
+        float* pp = part + ((((int64_t)b * Hkv + kvh) * nsplit + split) * G + g) * (HD + 2);
+        pp[d] = acc;
+        if (d == 0) { pp[HD] = m; pp[HD + 1] = l; }
+    }
+}
+
 // one wave per (b, q head): lanes over splits for the statistics, then over d for the accumulation
 template <int HD>
 __global__ __launch_bounds__(64) void decode_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ O, int Hq,
@@ -447,6 +657,19 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
                            (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
+                               (bf16_t*)O, Hq, Hkv, max_splits);
+    } else if ((int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {
+        constexpr int lds = 4 * 32768 + 4 * 8 * (128 + 2) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds128_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+        if (!direct)
+            hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     } else {
         hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,

@@ -297,13 +297,14 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("S", [70, 333, 129])
-def test_llm_prefill_then_decode_attention(dev, dt, S):
+def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     """llm_qkv_post (half-split RoPE, GQA, cache append incl. transposed V) + causal prefill attention, then two
     single-token decode steps with the kv length read from device memory."""
     from gar_amd import ops
     from oracle import gar_oracle as O
-    B, Hq, Hkv, hd = 2, 4, 2, 64
+    B, Hq, Hkv = 2, 4, 2
     Smax = (S + 8 + 63) // 64 * 64
     Wd = (Hq + 2 * Hkv) * hd
     pos = torch.arange(Smax, dtype=torch.float32)

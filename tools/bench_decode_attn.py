@@ -13,7 +13,8 @@ from gar_amd import hip, ops  # noqa: E402
 def main():
     hip.require_device(0)
     dev, dt = "cuda:0", torch.bfloat16
-    Hq, Hkv, hd, Smax, kv = 32, 8, 64, 4800, 4750
+    Hq, Hkv, Smax, kv = 32, 8, 4800, 4750
+    hd = int(os.environ.get("HD", "64"))    # 64: GAR-1B, 128: GAR-8B
     L = 4                                   # distinct caches so the stream comes from HBM
     for B in (16, 64):
         Kc = [torch.randn(B, Hkv, Smax, hd, device=dev).to(dt) for _ in range(L)]
