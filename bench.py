@@ -38,7 +38,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64,
                     help="regions per step per GPU (continuous batching of independent regions)")
-    ap.add_argument("--prefill-chunk", type=int, default=16, help="regions per vision-tower / prefill pass")
+    ap.add_argument("--prefill-chunk", type=int, default=0,
+                    help="0 (default): image tiles per vision-tower pass and sequences per prefill pass chosen by "
+                         "gar_amd/planner.py (whole rounds of the persistent tile GEMM); n > 0: both passes over chunks "
+                         "of n regions")
     ap.add_argument("--no-graph", action="store_true",
                     help="decode loop with eager launches instead of hipGraph replays (needed under rocprofv3 --pmc)")
     ap.add_argument("--new-tokens", type=int, default=64)
@@ -164,10 +167,10 @@ def main():
     W = None
     if rank == 0:
         W = synthetic_weights(cfg, seed=0)
-        model = GARModel(cfg, W, torch.bfloat16, device, prefill_chunk=args.prefill_chunk)
+        model = GARModel(cfg, W, torch.bfloat16, device, prefill_chunk=args.prefill_chunk or None)
     else:
         model = GARModel.from_shapes(cfg, torch.bfloat16, device)
-        model.prefill_chunk = args.prefill_chunk
+        model.prefill_chunk = args.prefill_chunk or None
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")
@@ -296,12 +299,13 @@ def main():
         wl = f"{mname} bf16, synthetic 1024x1024 images, 1 mask/region, {args.new_tokens}-token greedy caption " \
              f"(BASELINE.json {cfg_idx})"
     ids0 = batches[0]["input_ids"][0]
+    plan_v, plan_l = model._plan_passes(B, tiles, S)
     n_crop_rows = int(sum(int((ids0 == t).sum()) for t in (batches[0].get("video_frame_tokens") or cfg.crop_tokens_ids)))
     line = {"metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl,
-                       "regions_per_step_per_gpu": B, "prefill_chunk": args.prefill_chunk,
+                       "regions_per_step_per_gpu": B, "passes": {"vision_tower_tiles": plan_v, "prefill_sequences": plan_l},
                        "decode": "eager launches" if args.no_graph else "one hipGraph replay per token",
                        "tiles_per_region": tiles, "prefill_len": S,
                        "replayed_rows_per_region": n_crop_rows,

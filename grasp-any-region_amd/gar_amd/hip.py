@@ -110,6 +110,11 @@ def require_device(device_index: int = 0):
     check(lib().gar_check_device(device_index), "gar_check_device")
 
 
+def num_cus(device_index: int = 0) -> int:
+    """compute units of the device (the persistent tile GEMM launches one workgroup per CU: gar_amd/planner.py)."""
+    return int(torch.cuda.get_device_properties(device_index).multi_processor_count)
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return GAR_F32

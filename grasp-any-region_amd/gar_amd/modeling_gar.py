@@ -21,6 +21,7 @@ import torch
 
 from . import hip, ops
 from .configuration_gar import GARConfig
+from .planner import plan_chunks
 from .weights import LM, PJ, VT, check_weights, load_weights, normalize_checkpoint, synthetic_weights
 
 LOG2E = 1.4426950408889634
@@ -97,7 +98,7 @@ class GARModel:
     FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
 
     def __init__(self, config: GARConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
-                 device: str = "cuda:0", prefill_chunk: int = 16):
+                 device: str = "cuda:0", prefill_chunk: Optional[int] = None):
         self.device = torch.device(device)
         hip.require_device(self.device.index or 0)
         self.config = config
@@ -111,8 +112,10 @@ class GARModel:
         self._graphs: Dict[tuple, object] = {}
         self._llm_lru: List[tuple] = []
         self._video_crop_ids: Dict[tuple, torch.Tensor] = {}
-        # regions per vision-tower / prefill pass (decode serves all B at once); 10-16 measure within +-0.5 %
-        self.prefill_chunk = int(prefill_chunk)
+        # None: the vision tower runs over chunks of image TILES and the prefill over chunks of SEQUENCES, both chosen by
+        # gar_amd.planner so that the persistent tile GEMMs run whole rounds (decode serves all B at once).
+        # An int pins both passes to chunks of that many regions (the pre-planner behaviour; bench.py --prefill-chunk).
+        self.prefill_chunk = None if prefill_chunk is None else int(prefill_chunk)
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
@@ -281,9 +284,10 @@ class GARModel:
     # ---- vision tower + projector (A1-A6) -----------------------------------------------------------------------------
     @_on_model_device
     def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None,
-                           pooled: bool = True):
+                           pooled: bool = True, out: Optional[torch.Tensor] = None):
         """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l].
-        ``pooled=False`` stops after the projector and returns its [Tt * tokens, C_l] output (cls rows included)."""
+        ``pooled=False`` stops after the projector and returns its [Tt * tokens, C_l] output (cls rows included),
+        written into ``out`` when given."""
         cfg = self.config
         v = cfg.mllm_config.vision_config
         C_l = cfg.mllm_config.text_config.hidden_size
@@ -340,7 +344,8 @@ class GARModel:
         # projector over all N tokens of a tile (cls row included, dropped by the pooling window)
         p1 = f1.view(-1)[:Tt * N * C_l].view(Tt * N, C_l)
         ops.gemm(x2, self.pj["w1"], p1, hip.EPI_BIAS_GELU, bias=self.pj["b1"])
-        p2 = self._buf(key, "p2", (Tt * N, C_l))
+        p2 = self._buf(key, "p2", (Tt * N, C_l)) if out is None or pooled else out
+        assert tuple(p2.shape) == (Tt * N, C_l) and p2.is_contiguous()
         ops.gemm(p1, self.pj["w2"], p2, hip.EPI_BIAS, bias=self.pj["b2"])
         if cfg.mllm_config.projector_pooling_ratio != 2:
             raise hip.GarError("projector_pooling_ratio != 2 is not built")
@@ -568,6 +573,31 @@ class GARModel:
         ops.counter_add(st["counters"][0:3], 1)
         return logits
 
+    # ---- pass planning --------------------------------------------------------------------------------------------
+    VIT_CHUNK_ROWS = 400_000      # row caps of one vision-tower / prefill pass (activation workspaces: ~28 KB resp.
+    PREFILL_CHUNK_ROWS = 131_072  # ~38 KB per row for GAR-1B); the 4-GiB operand limit of the tile GEMM caps them too
+
+    def _plan_passes(self, B: int, tiles: int, S: int):
+        """(image tiles per vision-tower pass, sequences per prefill pass), see gar_amd/planner.py."""
+        if self.prefill_chunk is not None:
+            c = max(1, min(B, self.prefill_chunk))
+            seq = [min(c, B - b) for b in range(0, B, c)]
+            return [n * tiles for n in seq], seq
+        cfg = self.config
+        v, t = cfg.mllm_config.vision_config, cfg.mllm_config.text_config
+        cus = hip.num_cus(self.device.index or 0)
+        Da = v.num_heads * self.v_hd
+        vit_gemms = [(3 * Da, v.embed_dim), (v.embed_dim, Da), (v.mlp_dim, v.embed_dim), (v.embed_dim, v.mlp_dim)]
+        lim = (1 << 31) - 4096                 # A operand bytes / 2 addressable by the GEMM's buffer descriptor
+        vrows = min(self.VIT_CHUNK_ROWS, lim // max(v.mlp_dim, self.Kp, 3 * Da))
+        tile_chunks = plan_chunks(B * tiles, v.num_patches + self.npt, vit_gemms, vrows, cus) if tiles else []
+        qd = (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
+        llm_gemms = [(qd, t.hidden_size), (t.hidden_size, t.num_attention_heads * t.head_dim),
+                     (2 * t.intermediate_size, t.hidden_size), (t.hidden_size, t.intermediate_size)]
+        lrows = min(self.PREFILL_CHUNK_ROWS, lim // max(t.intermediate_size, qd))
+        seq_chunks = plan_chunks(B, S, llm_gemms, lrows, cus)
+        return tile_chunks, seq_chunks
+
     # ---- generate -------------------------------------------------------------------------------------------------
     @_on_model_device
     @torch.no_grad()
@@ -621,19 +651,35 @@ class GARModel:
                 # prompt_numbers ids are config.crop_tokens_ids, the following reserved tokens are consecutive ids
                 base = list(self.crop_tokens_ids)
                 video_frame_tokens = (base + [base[-1] + 1 + i for i in range(max(0, tiles - len(base)))])[:tiles]
-        # vision tower + prefill run over chunks of <= prefill_chunk regions (bounded activation memory, GEMM operands
-        # < 4 GiB); the decode loop below then serves all B sequences of the shared KV cache in one weight pass per token
+        # The vision tower runs over chunks of image tiles and the prefill over chunks of sequences (bounded activation
+        # memory, GEMM operands < 4 GiB; sizes from _plan_passes); the projector output of the whole batch is kept, and
+        # the decode loop below then serves all B sequences of the shared KV cache in one weight pass per token.
         first_logits = []
         self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
-        chunk = max(1, min(B, self.prefill_chunk))
-        for b0 in range(0, B, chunk):
-            b1 = min(B, b0 + chunk)
+        tile_chunks, seq_chunks = self._plan_passes(B, tiles, S)
+        proj_all, rows_per_sample = None, 0
+        if pixel_values is not None:
+            v = cfg.mllm_config.vision_config
+            C_l = cfg.mllm_config.text_config.hidden_size
+            rows_per_sample = tiles * (v.num_patches + self.npt)
+            proj_all = self._buf(("vit", "all"), "proj_all", (B * rows_per_sample, C_l))
+            pvf = pv.reshape(B * tiles, *pv.shape[-3:])
+            gmf = None if gm is None else gm.reshape(pvf.shape)
+            t0 = 0
+            for tc in tile_chunks:
+                r0, r1 = t0 * (v.num_patches + self.npt), (t0 + tc) * (v.num_patches + self.npt)
+                self.get_image_features(pvf[t0:t0 + tc], None if gmf is None else gmf[t0:t0 + tc], pooled=False,
+                                        out=proj_all[r0:r1])
+                t0 += tc
+        b0 = 0
+        for sc in seq_chunks:
+            b1 = b0 + sc
             ids_c = input_ids[b0:b1]
             if pixel_values is not None:
-                proj = self.get_image_features(pv[b0:b1], None if gm is None else gm[b0:b1], pooled=False)
                 ar_c = None if aspect_ratios is None else aspect_ratios[b0:b1]
                 embeds = self.build_inputs_embeds(ids_c, None, bboxes[b0:b1], ar_c, tiles, validate,
-                                                  video_frame_tokens if feature_replay_video else None, proj=proj)
+                                                  video_frame_tokens if feature_replay_video else None,
+                                                  proj=proj_all[b0 * rows_per_sample:b1 * rows_per_sample])
             else:
                 embeds = self._buf(("emb", b1 - b0, S), "embeds", (b1 - b0, S, cfg.mllm_config.text_config.hidden_size))
                 ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)
@@ -643,6 +689,7 @@ class GARModel:
                 st["cur"][b0:b1].copy_(forced_tokens[b0:b1, 0])
             if return_logits:
                 first_logits.append(lg[:, :V].float().clone())
+            b0 = b1
         all_logits = []
         if return_logits:
             all_logits.append(torch.cat(first_logits, 0))
