@@ -21,16 +21,27 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
           ("proj none", 139400, 1024, 1024, hip.EPI_NONE), ("proj bias", 139400, 1024, 1024, hip.EPI_BIAS),
           ("qkv none", 139400, 3072, 1024, hip.EPI_NONE), ("llm o none", 37744, 2048, 2048, hip.EPI_NONE)]
 
+# the planner's passes (gar_amd/planner.py, bench default): 387 image tiles x 1025 tokens, 26 sequences x 4718 tokens
+PLAN_SHAPES = [("vit qkv", 396675, 3072, 1024, hip.EPI_BIAS), ("vit proj", 396675, 1024, 1024, hip.EPI_BIAS_SCALE_RES),
+               ("vit fc1", 396675, 4096, 1024, hip.EPI_BIAS_GELU), ("vit fc2", 396675, 1024, 4096, hip.EPI_BIAS_SCALE_RES),
+               ("llm qkv", 122668, 3072, 2048, hip.EPI_NONE), ("llm o", 122668, 2048, 2048, hip.EPI_RES),
+               ("llm gate/up", 122668, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 122668, 2048, 8192, hip.EPI_RES)]
+
 
 def main():
     hip.require_device(0)
     dev = "cuda:0"
     reps = int(os.environ.get("REPS", "5"))
+    # PAD_A / PAD_C: extra elements in the row pitch of the A operand / of the output (+ residual): row-strided views
+    # (channel-camping experiment: power-of-two pitches put the 256 rows of a K tile on few HBM channels)
+    pad_a, pad_c = int(os.environ.get("PAD_A", "0")), int(os.environ.get("PAD_C", "0"))
     tot_f = tot_t = 0.0
-    for name, M, N, K, epi in SHAPES[:int(os.environ.get("SHAPES", "99"))]:
-        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    shapes = PLAN_SHAPES if os.environ.get("SHAPESET") == "plan" else SHAPES
+    for name, M, N, K, epi in shapes[:int(os.environ.get("SHAPES", "99"))]:
+        a = torch.randn(M, K + pad_a, device=dev).to(torch.bfloat16)[:, :K]
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
-        out = torch.empty(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
+        No = N // 2 if epi == hip.EPI_SWIGLU else N
+        out = torch.empty(M, No + pad_c, device=dev, dtype=torch.bfloat16)[:, :No]
         kw = {}
         if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
@@ -51,7 +62,7 @@ def main():
         tot_f += fl
         tot_t += ms
         print(f"{name:12s} M={M:6d} N={N:5d} K={K:4d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
-    print(f"weighted: {tot_f / tot_t / 1e9:.1f} TFLOP/s  (library: {os.environ.get('GAR_HIP_LIB', 'product')})")
+    print(f"weighted: {tot_f / tot_t / 1e9:.1f} TFLOP/s  (library: {os.environ.get('GAR_HIP_LIB', 'product')}, PAD_A={pad_a} PAD_C={pad_c})")
 
 
 if __name__ == "__main__":
