@@ -56,6 +56,9 @@ def parse():
                     help="resident (default, the bench contract): model inputs already in HBM. device: every step also "
                          "builds its B samples from host PIL images + masks (id matrix, bbox, prompt ids, H2D of the "
                          "raw uint8 image, resize/tile/normalise kernels of preprocess.hip) inside the timed region")
+    ap.add_argument("--no-patch-gather", action="store_true",
+                    help="A/B: patch-embed as gar_patch_im2col + GEMM instead of gar_patch_embed (patches DMA'd from the "
+                         "image tiles into LDS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args()
@@ -171,6 +174,8 @@ def main():
     else:
         model = GARModel.from_shapes(cfg, torch.bfloat16, device)
         model.prefill_chunk = args.prefill_chunk or None
+    if args.no_patch_gather:
+        model.w_patch_gather = None
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")

@@ -89,8 +89,25 @@ __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
     return x >= 8.0f ? x : y;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n) {
+// Patch gather (GATHER, GAR_EPI_PATCH_POS only — gar_patch_embed): the A operand is not a matrix in HBM but the image
+// tiles themselves. Row m = patch (tile, py, px) of a g x g = 32 x 32 patch grid; the K axis is re-ordered (and the
+// weights with it, gar_patch_embed_weight_index) as  [tensor: pixel, mask][channel 0-2][q 0-3][ky = 4q + 0..3][16 kx slots],
+// i.e. one K tile of 64 = four image rows of a patch x 16 pixel slots (patch <= 16 real ones, the rest meet zero weights).
+// A lane's 16-byte DMA chunk is then 8 consecutive pixels of one image row — `buffer_load_dwordx4 ... lds` needs dword
+// alignment only — 8 neighbouring patches are 8 * patch * 2 contiguous bytes of that row, 64 rows further down the tile
+// are two patch rows further down the image, and a 256-row tile never leaves its image tile: the per-lane offset stays
+// one VGPR and everything else scalar, exactly as for a dense A. The (c, ky) rows 14 / 15 and pixel slots 14 / 15 read
+// the neighbouring patch / image row (finite data x zero weight; past the end of the tensor the descriptor returns 0).
+struct gar_gather_args {
+    const void* mask;      // binary mask, same [T, 3, img, img] layout as the pixels in p.A
+    int img, patch;        // image side, patch side (g = img / patch == 32)
+    unsigned bytes;        // T * 3 * img * img * 2
+};
+#define GATHER_KT_PER_TENSOR 12     // 3 channels x 4 K tiles (16 ky slots)
+
+template <int EPI, bool GATHER = false>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_params p, int tiles_m, int tiles_n,
+                                                              const gar_gather_args ga) {
     constexpr bool PERM = EPI != GAR_EPI_SWIGLU;      // SwiGLU pairs (gate16 | up16) weight tiles and stores from the fragments
     constexpr bool LDS_EPI = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 64 KiB (+ the GELU table)
@@ -116,19 +133,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     f32x4 acc[8][4];
     bf16x8 af[4], bq[4];              // current A fragments (4 m-tiles of one half, one k-step), B fragments (4 n-tiles, one k-step)
 
-    const unsigned rbA = (unsigned)p.lda * 2u, rbW = (unsigned)p.ldw * 2u;      // row pitch in bytes
+    // row pitch in bytes (GATHER: 32 rows = one patch row of the image = patch * img * 2 bytes)
+    const unsigned g_rb = GATHER ? (unsigned)ga.img * 2u : 0u;                  // image row
+    const unsigned rbA = GATHER ? (unsigned)ga.patch * g_rb / 32u : (unsigned)p.lda * 2u, rbW = (unsigned)p.ldw * 2u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)A, 0, (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+        (void*)A, 0, GATHER ? (int)ga.bytes : (int)(((int64_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = GATHER ? __builtin_amdgcn_make_buffer_rsrc((void*)ga.mask, 0, (int)ga.bytes, 0x00020000) : rsA;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
     const int sub = lane >> 3;
     const int keyW = PERM ? (((wave & 3) << 1) | ((sub >> 1) & 1)) : sub;
-    const int voffA = (int)((unsigned)(wave * 8 + sub) * rbA) + (((lane & 7) ^ sub) << 4);
+    int voffA = (int)((unsigned)(wave * 8 + sub) * rbA) + (((lane & 7) ^ sub) << 4);
+    if (GATHER) {       // row r = wave * 8 + sub of a 64-row block: patch (r >> 5, r & 31); chunk c8 = (image row c8 >> 1, half c8 & 1)
+        const int r = wave * 8 + sub, c8 = (lane & 7) ^ sub;
+        voffA = (int)((unsigned)(r >> 5) * (unsigned)ga.patch * g_rb + (unsigned)(r & 31) * (unsigned)ga.patch * 2u +
+                      (unsigned)(c8 >> 1) * g_rb + (unsigned)(c8 & 1) * 16u);
+    }
+    // GATHER: byte offset of (first row m of a tile, K tile t) in its tensor, and which tensor
+    auto g_base = [&](int m, int t) -> unsigned {
+        const int ti = m >> 10, pr0 = (m & 1023) >> 5;
+        const int tt = t >= GATHER_KT_PER_TENSOR ? t - GATHER_KT_PER_TENSOR : t;
+        return ((unsigned)((ti * 3 + (tt >> 2)) * ga.img + pr0 * ga.patch + ((tt & 3) << 2))) * g_rb;
+    };
     const int voffW = (int)((unsigned)(wave * 8 + sub) * rbW) + (((lane & 7) ^ keyW) << 4);
     auto stage_A = [&](int m0, int t, char* st) {
-        const unsigned base = (unsigned)m0 * rbA + (unsigned)(t * PBK * 2);
-        stage_half(rsA, voffA, rbA, base, st, wave);
-        stage_half(rsA, voffA, rbA, base + 128u * rbA, st + PHALF, wave);
+        const unsigned base = GATHER ? g_base(m0, t) : (unsigned)m0 * rbA + (unsigned)(t * PBK * 2);
+        const __amdgpu_buffer_rsrc_t rs = GATHER && t >= GATHER_KT_PER_TENSOR ? rsA2 : rsA;
+        stage_half(rs, voffA, rbA, base, st, wave);
+        stage_half(rs, voffA, rbA, base + 128u * rbA, st + PHALF, wave);
     };
     auto stage_W = [&](int n0, int t, char* st) {
         const unsigned base = (unsigned)n0 * rbW + (unsigned)(t * PBK * 2);
@@ -655,11 +687,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         int rb = sidx * PSTAGE + b_row + cb0;
         char* nx = smem + (sidx ^ 1) * PSTAGE;               // stage being filled
         unsigned bA, bW;                                     // global byte offsets of the K tile being prefetched
+        __amdgpu_buffer_rsrc_t rsAc = rsA;                   // GATHER: the tensor (pixels / mask) that K tile comes from
         {
             const bool last = nt == 1;
             const int pm = last ? m0n : m0, pn = last ? n0n : n0, pt = last ? 0 : 1;
-            bA = (unsigned)pm * rbA + (unsigned)(pt * PBK * 2);
+            bA = GATHER ? g_base(pm, pt) : (unsigned)pm * rbA + (unsigned)(pt * PBK * 2);
             bW = (unsigned)pn * rbW + (unsigned)(pt * PBK * 2);
+            if (GATHER) rsAc = pt >= GATHER_KT_PER_TENSOR ? rsA2 : rsA;
         }
         // Four phases per K tile = (k-step, 64-row half of the wave's A rows): 8 + 4 + 8 + 4 fragment reads.
         // The eight 1-KiB DMAs a wave issues per K tile go out 1 + 4 + 2 + 1 over the phases, ordered by when their 8-KiB
@@ -675,10 +709,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #define DMA_B dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 1);
 #define DMA_C dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 0);
 #define DMA_D dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 1);
-#define DMA_E dma1(rsA, voffA, rbA, bA, nx, wave, 0);
-#define DMA_F dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
-#define DMA_G dma1(rsA, voffA, rbA, bA, nx, wave, 1);
-#define DMA_H dma1(rsA, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
+#define DMA_E dma1(rsAc, voffA, rbA, bA, nx, wave, 0);
+#define DMA_F dma1(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
+#define DMA_G dma1(rsAc, voffA, rbA, bA, nx, wave, 1);
+#define DMA_H dma1(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
 // 1 + 4 + 2 + 1 (1 5 2 0 and 0 5 2 1 measured within noise of it)
 #define L0_DMA DMA_A
 #define L1_DMA DMA_B DMA_C DMA_D DMA_E
@@ -727,8 +761,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         {                                                                                                            \
             const bool last_ = (kt) + 2 >= nt;                                                                       \
             const int pm_ = last_ ? m0n : m0, pn_ = last_ ? n0n : n0, pt_ = last_ ? 0 : (kt) + 2;                    \
-            bA = (unsigned)pm_ * rbA + (unsigned)(pt_ * PBK * 2);                                                    \
+            bA = GATHER ? g_base(pm_, pt_) : (unsigned)pm_ * rbA + (unsigned)(pt_ * PBK * 2);                       \
             bW = (unsigned)pn_ * rbW + (unsigned)(pt_ * PBK * 2);                                                    \
+            if (GATHER) rsAc = pt_ >= GATHER_KT_PER_TENSOR ? rsA2 : rsA;                                             \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
@@ -828,16 +863,77 @@ static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hip
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(min(pm * pn, num_cus)), dim3(512), LDS, s, p, pm, pn);   // persistent
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(min(pm * pn, num_cus)), dim3(512), LDS, s, p, pm, pn,
+                       gar_gather_args{});                                                                      // persistent
 }
 
-// returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel
-bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
+static int pp_num_cus() {
     static const int num_cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
+    return num_cus;
+}
+
+// Patch-embed + mask-embed convolutions with the patches DMA'd from the image tiles into LDS (see the GATHER notes above).
+// x[t, token_offset + patch, :] = [pixel patch | mask patch] Wg^T + pos[token_offset + patch].  Returns GAR_ERR_UNSUPPORTED
+// for shapes the gather form is not built for (the caller keeps gar_patch_im2col + gar_gemm).
+extern "C" int gar_patch_embed_k(int img, int patch) {
+    (void)img;
+    return patch > 0 && patch <= 16 ? 2 * GATHER_KT_PER_TENSOR * PBK : 0;
+}
+
+extern "C" int gar_patch_embed(int dtype, const void* pixel, const void* maskbin, const void* Wg, const void* pos, void* x,
+                               int T_, int img, int patch, int D, int tokens_out, int token_offset, gar_stream_t stream) {
+    GAR_CHECK_ARG(pixel && maskbin && Wg && pos && x && T_ > 0 && D > 0, "patch_embed: null pointer / bad shape");
+    const int g = patch > 0 ? img / patch : 0;
+    const int64_t bytes = (int64_t)T_ * 3 * img * img * 2;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const int pm = T_ * g * g / PBM, pn = (D + PBM - 1) / PBM;
+    if (dtype != GAR_BF16 || g != 32 || img != g * patch || patch > 16 || (patch & 1) || (patch * img * 2) % 32 != 0 ||
+        bytes >= ((int64_t)1 << 32) - 4096 || D % 8 != 0 || D < 256 || pm * pn < 128 || !al16(pixel) || !al16(maskbin) ||
+        !al16(Wg) || !al16(pos) || !al16(x) || tokens_out < g * g + token_offset || token_offset < 0) {
+        gar_set_error("patch_embed: the gather form is built for bf16, a 32 x 32 grid of even patches <= 16 px, >= 128 output "
+                      "tiles (T=%d img=%d patch=%d D=%d)", T_, img, patch, D);
+        return GAR_ERR_UNSUPPORTED;
+    }
+    gar_gemm_params p = {};
+    p.A = pixel;
+    p.W = Wg;
+    p.K = 2 * GATHER_KT_PER_TENSOR * PBK;
+    p.ldw = p.K;
+    p.lda = p.K;                            // unused by the gather form
+    p.C = x;
+    p.ldc = D;
+    p.M = T_ * g * g;
+    p.N = D;
+    p.epilogue = GAR_EPI_PATCH_POS;
+    p.pos = pos;
+    p.tokens_in = g * g;
+    p.tokens_out = tokens_out;
+    p.token_offset = token_offset;
+    gar_gather_args ga;
+    ga.mask = maskbin;
+    ga.img = img;
+    ga.patch = patch;
+    ga.bytes = (unsigned)bytes;
+    constexpr int LDS = 2 * PSTAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>), dim3(min(pm * pn, pp_num_cus())), dim3(512), LDS,
+                       (hipStream_t)stream, p, pm, pn, ga);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel
+bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
+    const int num_cus = pp_num_cus();
     const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
     if (pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
     // the row-coalesced epilogue moves 16-byte vectors of C / residual / bias / gamma / pos

@@ -69,6 +69,34 @@ extern "C" int gar_patch_im2col(int dtype, const void* pixel, const void* mask, 
     return GAR_OK;
 }
 
+// mask decode alone (A1), for gar_patch_embed: 8 elements per thread, 16-byte accesses (bf16) — reads the processor's
+// [-1, 1] encoding once, writes the {0, 1} mask once.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_decode_kernel(const T* __restrict__ mask, T* __restrict__ out, int64_t n8, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    ld8(mask + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = mask_binary<T>(v[e], P);
+    st8(out + i * 8, v);
+}
+
+extern "C" int gar_mask_decode(int dtype, const void* mask, void* out, int64_t n, int prompt_numbers, gar_stream_t stream) {
+    GAR_CHECK_ARG(dtype == GAR_F32 || dtype == GAR_BF16, "mask_decode: bad dtype");
+    GAR_CHECK_ARG(mask && out && n > 0 && n % 8 == 0, "mask_decode: n=%lld must be a positive multiple of 8", (long long)n);
+    GAR_CHECK_ARG(((uintptr_t)mask % 16) == 0 && ((uintptr_t)out % 16) == 0, "mask_decode: 16-byte aligned pointers");
+    const int64_t n8 = n / 8;
+    dim3 grid((unsigned)((n8 + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((mask_decode_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)mask, (bf16_t*)out, n8, prompt_numbers);
+    else
+        hipLaunchKernelGGL((mask_decode_kernel<float>), grid, block, 0, s, (const float*)mask, (float*)out, n8, prompt_numbers);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void cls_pos_fill_kernel(T* x, const T* cls, const T* pos, int T_, int tokens, int D) {

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
 GAR_F32, GAR_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GarError(RuntimeError):
@@ -40,6 +40,9 @@ SIGNATURES = {
     "gar_check_device": ([_i], _i),
     "gar_gemm": ([_i, C.POINTER(GemmParams), _vp], _i),
     "gar_patch_im2col": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "gar_mask_decode": ([_i, _vp, _vp, _i64, _i, _vp], _i),
+    "gar_patch_embed_k": ([_i, _i], _i),
+    "gar_patch_embed": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "gar_cls_pos_fill": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "gar_layernorm": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
     "gar_rmsnorm": ([_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),

@@ -141,6 +141,8 @@ class GARModel:
         ts = [self.w_patch, self.pos, *self.norm_pre, *self.pj.values(), self.E, self.final_norm]
         if self.cls is not None:
             ts.append(self.cls)
+        if self.w_patch_gather is not None:
+            ts.append(self.w_patch_gather)
         if self.lm_head is not self.E:
             ts.append(self.lm_head)
         for blk in self.vblocks:
@@ -173,6 +175,18 @@ class GARModel:
         wcat[:, 3 * pp:6 * pp] = W["mask_patch_embedding.weight"].float().flatten(1)
         d = self._dev
         self.w_patch = d(wcat)
+        # the same two conv weights in the K order of gar_patch_embed (patches gathered from the image tiles by the GEMM's
+        # DMA): column ((tensor*3 + c)*4 + ky//4)*64 + (ky%4)*16 + kx; zero in the slots no pixel of the patch maps to
+        self.w_patch_gather = None
+        P_ = v.patch_size
+        Kg = ops.patch_embed_k(v.img_size, P_) if self.dtype == torch.bfloat16 else 0
+        if Kg:
+            wg = torch.zeros(D, 2, 3, 4, 4, 16, dtype=torch.float32, device=wcat.device)
+            for ti, key in enumerate((VT + "patch_embed.proj.weight", "mask_patch_embedding.weight")):
+                w4 = torch.zeros(D, 3, 16, 16, dtype=torch.float32, device=wcat.device)
+                w4[:, :, :P_, :P_] = W[key].float()
+                wg[:, ti] = w4.view(D, 3, 4, 4, 16)
+            self.w_patch_gather = d(wg.view(D, Kg))
         self.npt = 1 if cfg.mllm_config.vision_use_cls_token else 0
         self.cls = d(W[VT + "cls_token"].reshape(-1)) if self.npt else None
         self.pos = d(W[VT + "pos_embed"].reshape(-1, D))
@@ -304,7 +318,6 @@ class GARModel:
         N = n + self.npt
         Npad = _round_up(N, 64)
         key = ("vit", Tt)
-        A = self._buf(key, "im2col", (Tt * n, self.Kp))
         x = self._buf(key, "x", (Tt, N, D))
         hbuf = self._buf(key, "h", (Tt * N, D))
         qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
@@ -318,9 +331,21 @@ class GARModel:
         fused = self.dtype == torch.bfloat16
         vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
-        ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
         x2 = x.view(Tt * N, D)
-        ops.gemm(A, self.w_patch, x2, hip.EPI_PATCH_POS, pos=self.pos, tokens_in=n, tokens_out=N, token_offset=self.npt)
+        gathered = False
+        if self.w_patch_gather is not None:
+            # patches DMA'd from the image tiles into LDS by the GEMM itself: no im2col matrix (1216 columns per patch
+            # written and re-read); the mask decode is one elementwise pass
+            mb = self._buf(key, "maskbin", tuple(pix.shape))
+            if msk is not None:
+                ops.mask_decode(msk, mb, cfg.prompt_numbers)
+            else:
+                mb.zero_()
+            gathered = ops.patch_embed(pix, mb, self.w_patch_gather, self.pos, x, v.patch_size, self.npt)
+        if not gathered:
+            A = self._buf(key, "im2col", (Tt * n, self.Kp))
+            ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
+            ops.gemm(A, self.w_patch, x2, hip.EPI_PATCH_POS, pos=self.pos, tokens_in=n, tokens_out=N, token_offset=self.npt)
         if self.npt:
             ops.cls_pos_fill(x, self.cls, self.pos)
         ops.layernorm(x2, *self.norm_pre, v.ln_eps)

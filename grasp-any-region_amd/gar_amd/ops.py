@@ -89,6 +89,49 @@ def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[
     return h
 
 
+def mask_decode(mask: torch.Tensor, out: torch.Tensor, prompt_numbers: int):
+    """out = (clamp(round((mask + 1) / 2 * 255), 0, P) != P) in the tensor's dtype (modeling_gar.py:315-327)."""
+    _chk(mask, "mask")
+    assert out.shape == mask.shape and out.dtype == mask.dtype and out.is_contiguous()
+    check(lib().gar_mask_decode(dtype_code(mask.dtype), ptr(mask), ptr(out), mask.numel(), prompt_numbers, stream()),
+          "gar_mask_decode")
+    return out
+
+
+def patch_embed_k(img: int, patch: int) -> int:
+    """K of the gather-ordered patch-embed weight (0: the gather form is not built for this patch size)."""
+    return int(lib().gar_patch_embed_k(img, patch))
+
+
+def patch_embed(pixel: torch.Tensor, maskbin: torch.Tensor, w_gather: torch.Tensor, pos: torch.Tensor, x: torch.Tensor,
+                patch: int, token_offset: int) -> bool:
+    """x[t, token_offset + p, :] = patch-embed(pixel) + mask-embed(maskbin) + pos, the patches DMA'd from the image tiles
+    [T, 3, img, img] into LDS by the tile GEMM (no im2col matrix). False when the library does not take the shape on this
+    path (nothing launched; the caller keeps patch_im2col + gemm(EPI_PATCH_POS))."""
+    _chk(pixel, "pixel")
+    _chk(maskbin, "maskbin")
+    T, c, img, _ = pixel.shape
+    assert c == 3 and maskbin.shape == pixel.shape and x.dim() == 3 and x.is_contiguous() and x.shape[0] == T
+    D = x.shape[2]
+    assert w_gather.is_contiguous() and w_gather.shape[0] == D and pos.is_contiguous() and pos.shape[1] == D
+    prof = KERNEL_TIMERS
+    timed = prof is not None and not torch.cuda.is_current_stream_capturing()
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().gar_patch_embed(dtype_code(pixel.dtype), ptr(pixel), ptr(maskbin), ptr(w_gather), ptr(pos), ptr(x), T, img,
+                               patch, D, x.shape[1], token_offset, stream())
+    if rc == hip.ERR_UNSUPPORTED:
+        return False
+    check(rc, "gar_patch_embed")
+    if timed:
+        e1.record()
+        g = img // patch
+        M, K = T * g * g, 6 * patch * patch       # algorithmic K (the gather's zero-weight slots are not counted)
+        prof.append(("gemm_tile_bf16", 2.0 * M * D * K, (T * 6 * img * img + D * K + M * D) * 2, e0, e1))
+    return True
+
+
 def patch_im2col(pixel: torch.Tensor, mask: Optional[torch.Tensor], out: torch.Tensor, patch: int, prompt_numbers: int):
     _chk(pixel, "pixel")
     T, c, img, _ = pixel.shape

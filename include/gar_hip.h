@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 4
+#define GAR_ABI_VERSION 5
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -100,6 +100,23 @@ int gar_gemm(int dtype, const gar_gemm_params* p, gar_stream_t stream);
  * `mask` may be NULL (then the mask columns are 0). */
 int gar_patch_im2col(int dtype, const void* pixel, const void* mask, void* out, int T, int img, int patch,
                      int Kp, int prompt_numbers, gar_stream_t stream);
+
+/* A1 alone: out = (clamp(round((m+1)/2*255), 0, P) != P) ? 1 : 0 in the tensor's dtype, elementwise over n elements
+ * (n % 8 == 0) — the mask decode of modeling_gar.py:315-327 for gar_patch_embed, which reads the images in place. */
+int gar_mask_decode(int dtype, const void* mask, void* out, int64_t n, int prompt_numbers, gar_stream_t stream);
+
+/* A2 + K2 with the patch tiles DMA'd from the image tiles straight into LDS (bf16 tile GEMM; no im2col matrix in HBM):
+ *   x[t, token_offset + (py*g + px), :] = conv14(pixel)[t, :, py, px] + conv14(maskbin)[t, :, py, px] + pos[token_offset + py*g + px]
+ * i.e. `mask_patch_embedding` (modeling_gar.py:54-60,326-328) + timm PatchEmbed + `x + mask_embeds` + pos_embed
+ * (modeling_perception_lm.py:194-197) as ONE GEMM whose A operand is gathered from `pixel` / `maskbin`
+ * [T, 3, img, img] (maskbin = gar_mask_decode output). Wg [D, gar_patch_embed_k(img, patch)] holds both conv weights in the
+ * gather's K order: column ((tensor*3 + c)*4 + ky/4)*64 + (ky%4)*16 + kx  <-  W_tensor[d, c, ky, kx], zero elsewhere
+ * (tensor 0 = patch_embed.proj, 1 = mask_patch_embedding). x rows have pitch D, tiles have tokens_out rows.
+ * Returns GAR_ERR_UNSUPPORTED (nothing launched) unless bf16, img / patch == 32, patch even and <= 16, and the
+ * problem has >= 128 output tiles of 256 x 256; the caller then uses gar_patch_im2col + gar_gemm(GAR_EPI_PATCH_POS). */
+int gar_patch_embed_k(int img, int patch);
+int gar_patch_embed(int dtype, const void* pixel, const void* maskbin, const void* Wg, const void* pos, void* x, int T,
+                    int img, int patch, int D, int tokens_out, int token_offset, gar_stream_t stream);
 
 /* cls token row: x[t, 0, :] = cls + pos[0]   (timm Eva._pos_embed, via modeling_perception_lm.py:197) */
 int gar_cls_pos_fill(int dtype, void* x, const void* cls, const void* pos, int T, int tokens, int D,

@@ -242,6 +242,74 @@ def test_patch_embed_with_mask_matches_two_convs(dev, dt):
     assert torch.equal(Ah, bref)
 
 
+@pytest.mark.parametrize("T,npt,with_mask", [(9, 1, True), (8, 0, True), (9, 1, False)])
+def test_patch_embed_gather_matches_two_convs(dev, T, npt, with_mask):
+    """gar_mask_decode + gar_patch_embed (patches DMA'd from the image tiles into LDS by the tile GEMM, weights in the
+    gather's K order) == patch-embed conv + mask conv + pos embed in fp64, and == the im2col + GEMM path within bf16
+    rounding; reads that stray out of the tensor with a non-zero weight would show (neighbour images hold 1e4)."""
+    from gar_amd import hip, ops
+    from oracle import gar_oracle as O
+    dt = torch.bfloat16
+    img, patch, D, P = 448, 14, 1024, 5
+    g = img // patch
+    n = g * g
+    Kg = ops.patch_embed_k(img, patch)
+    assert Kg == 1536
+    pix = q(rnd(T, 3, img, img, seed=23), dt)
+    ids = torch.randint(0, 8, (T, 3, img, img), generator=torch.Generator().manual_seed(24))      # channels differ
+    mvals = q((ids.float() / 255.0 - 0.5) / 0.5, dt)
+    wp, wm = q(rnd(D, 3, patch, patch, seed=25, scale=0.05), dt), q(rnd(D, 3, patch, patch, seed=26, scale=0.05), dt)
+    pos = q(rnd(n + npt, D, seed=27, scale=0.2), dt)
+    wg = torch.zeros(D, 2, 3, 16, 16)
+    wg[:, 0, :, :patch, :patch] = wp
+    wg[:, 1, :, :patch, :patch] = wm
+    wg = wg.view(D, 2, 3, 4, 4, 16).reshape(D, Kg)
+    big = torch.full((T + 2, 3, img, img), 1e4, dtype=dt, device=dev)
+    big[1:T + 1] = pix.to(dev, dt)
+    pixd = big[1:T + 1]
+    binary = O.decode_mask_values(mvals.to(dt), P) if with_mask else torch.zeros_like(mvals)
+    mb = torch.empty(T, 3, img, img, dtype=dt, device=dev)
+    if with_mask:
+        ops.mask_decode(mvals.to(dev, dt), mb, P)
+        assert torch.equal(mb.cpu().float(), binary.float())                  # A1 alone: bit-exact
+    else:
+        mb.zero_()
+    x = torch.zeros(T, n + npt, D, dtype=dt, device=dev)
+    assert ops.patch_embed(pixd, mb, wg.to(dev, dt), pos.to(dev, dt), x, patch, npt)
+    torch.cuda.synchronize()
+    ref = F.conv2d(pix.double(), wp.double(), stride=patch) + F.conv2d(binary.double(), wm.double(), stride=patch)
+    ref = ref.flatten(2).transpose(1, 2) + pos[npt:].double()
+    close(x[:, npt:], ref, dt)
+    if npt:
+        assert float(x[:, 0].float().abs().max()) == 0.0                      # cls rows untouched
+    # the im2col form of the same product (different K order: fp32 sums may differ in the last bits before rounding)
+    Kp = (6 * patch * patch + 63) // 64 * 64
+    wcat = torch.zeros(D, Kp)
+    wcat[:, :3 * patch * patch] = wp.flatten(1)
+    wcat[:, 3 * patch * patch:6 * patch * patch] = wm.flatten(1)
+    A = torch.empty(T * n, Kp, dtype=dt, device=dev)
+    ops.patch_im2col(pixd.contiguous(), mvals.to(dev, dt) if with_mask else None, A, patch, P)
+    x2 = torch.zeros(T, n + npt, D, dtype=dt, device=dev)
+    ops.gemm(A, wcat.to(dev, dt), x2.view(T * (n + npt), D), hip.EPI_PATCH_POS, pos=pos.to(dev, dt), tokens_in=n,
+             tokens_out=n + npt, token_offset=npt)
+    d = (x.float() - x2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(x2.float().abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.05                               # rare last-bit flips only
+
+
+def test_patch_embed_gather_refuses_other_shapes(dev):
+    from gar_amd import ops
+    dt = torch.bfloat16
+    for T, img, patch, D in [(3, 56, 14, 64), (2, 448, 14, 512), (9, 512, 16, 1024)]:      # grid 4; < 128 tiles; taken
+        pix = torch.zeros(T, 3, img, img, dtype=dt, device=dev)
+        n = (img // patch) ** 2
+        x = torch.zeros(T, n, D, dtype=dt, device=dev)
+        Kg = ops.patch_embed_k(img, patch)
+        took = ops.patch_embed(pix, pix, torch.zeros(D, Kg, dtype=dt, device=dev), torch.zeros(n, D, dtype=dt, device=dev),
+                               x, patch, 0)
+        assert took == (img == 512)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_pool2x2_with_cls_window(dev, dt):
     from gar_amd import ops
