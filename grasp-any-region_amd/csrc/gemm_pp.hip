@@ -58,19 +58,27 @@
 // `buffer_load_dwordx4 ... lds` through a buffer descriptor: the per-lane part of the address is ONE 32-bit VGPR
 // (voff = byte offset of (row = 8*wave + lane/8, 16-B chunk (lane&7)^key) inside a tile), everything else is scalar,
 // and rows past the end of the tensor (M / N tails) are zero-filled by the descriptor's bounds check.
+#ifndef PP_A_AUX          /* diagnostic builds: cache-policy bits of the A-operand DMA loads (2 = nt: stream through the L2) */
+#define PP_A_AUX 0
+#endif
+#ifndef PP_W_AUX
+#define PP_W_AUX 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base,
                                            char* lds, int wave) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_AS(lds + (i * 8 + wave) * 1024), 16,
-                                                 voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
+                                                 voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, AUX);
 }
 
 // one of the two instructions of stage_half: i = 0 -> rows 8*wave .. +7, i = 1 -> rows 64 + 8*wave .. +7 of the 128-row half
+template <int AUX = 0>
 __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base, char* lds,
                                      int wave, int i) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_AS(lds + (i * 8 + wave) * 1024), 16,
-                                             voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, 0);
+                                             voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, AUX);
 }
 
 // GELU by table (BIAS_GELU epilogue): the erf GELU of a 256 x 256 tile costs ~46 VALU cycles per element as A&S 7.1.26
@@ -159,13 +167,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     auto stage_A = [&](int m0, int t, char* st) {
         const unsigned base = GATHER ? g_base(m0, t) : (unsigned)m0 * rbA + (unsigned)(t * PBK * 2);
         const __amdgpu_buffer_rsrc_t rs = GATHER && t >= GATHER_KT_PER_TENSOR ? rsA2 : rsA;
-        stage_half(rs, voffA, rbA, base, st, wave);
-        stage_half(rs, voffA, rbA, base + 128u * rbA, st + PHALF, wave);
+        stage_half<PP_A_AUX>(rs, voffA, rbA, base, st, wave);
+        stage_half<PP_A_AUX>(rs, voffA, rbA, base + 128u * rbA, st + PHALF, wave);
     };
     auto stage_W = [&](int n0, int t, char* st) {
         const unsigned base = (unsigned)n0 * rbW + (unsigned)(t * PBK * 2);
-        stage_half(rsW, voffW, rbW, base, st + 2 * PHALF, wave);
-        stage_half(rsW, voffW, rbW, base + 128u * rbW, st + 3 * PHALF, wave);
+        stage_half<PP_W_AUX>(rsW, voffW, rbW, base, st + 2 * PHALF, wave);
+        stage_half<PP_W_AUX>(rsW, voffW, rbW, base + 128u * rbW, st + 3 * PHALF, wave);
     };
 
 #ifdef PP_DEPHASE   /* diagnostic build (tools/runs/r2_measure3.sh): workgroups on odd XCDs (PP_DEPHASE = 1) or on odd CU slots of
@@ -535,18 +543,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) sc[0][t][hf] = sc_load(0, t, hf);
         }
-        u32x4 aux[3][2];
+#ifndef PP_AUX_AHEAD      /* 16-row steps the row-dependent loads run ahead of their use (ring of PP_AUX_AHEAD + 1 slots) */
+#define PP_AUX_AHEAD 2
+#endif
+        constexpr int AH = PP_AUX_AHEAD;
+        u32x4 aux[AH + 1][2];
         if (HAS_AUX) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < AH; ++i)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) aux[i][t] = aux_load(i, t);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (HAS_AUX && i + 2 < 8) {
+            if (HAS_AUX && i + AH < 8) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) aux[(i + 2) % 3][t] = aux_load(i + 2, t);
+                for (int t = 0; t < 2; ++t) aux[(i + AH) % (AH + 1)][t] = aux_load(i + AH, t);
             }
             if (QKV && i + 1 < 8) {
 #pragma unroll
@@ -621,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             for (int e = 0; e < 8; ++e) o[e] += bias8[e];
                         }
                         if (HAS_AUX) {
-                            const u32x4 w = aux[i % 3][t];
+                            const u32x4 w = aux[i % (AH + 1)][t];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
@@ -705,14 +717,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // ahead of each first read; the same counts are right for both rows (row 1 runs the same program one interval
         // later, so the count its deadline needs is never looser than row 0's at the same program point).
         // After the very last tile m0n = n0n = 0: a harmless prefetch nobody reads keeps the phases branch-free.
-#define DMA_A dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 0);
-#define DMA_B dma1(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 1);
-#define DMA_C dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 0);
-#define DMA_D dma1(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 1);
-#define DMA_E dma1(rsAc, voffA, rbA, bA, nx, wave, 0);
-#define DMA_F dma1(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
-#define DMA_G dma1(rsAc, voffA, rbA, bA, nx, wave, 1);
-#define DMA_H dma1(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
+#define DMA_A dma1<PP_W_AUX>(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 0);
+#define DMA_B dma1<PP_W_AUX>(rsW, voffW, rbW, bW, nx + 2 * PHALF, wave, 1);
+#define DMA_C dma1<PP_W_AUX>(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 0);
+#define DMA_D dma1<PP_W_AUX>(rsW, voffW, rbW, bW + 128u * rbW, nx + 3 * PHALF, wave, 1);
+#define DMA_E dma1<PP_A_AUX>(rsAc, voffA, rbA, bA, nx, wave, 0);
+#define DMA_F dma1<PP_A_AUX>(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 0);
+#define DMA_G dma1<PP_A_AUX>(rsAc, voffA, rbA, bA, nx, wave, 1);
+#define DMA_H dma1<PP_A_AUX>(rsAc, voffA, rbA, bA + 128u * rbA, nx + PHALF, wave, 1);
 // 1 + 4 + 2 + 1 (1 5 2 0 and 0 5 2 1 measured within noise of it)
 #define L0_DMA DMA_A
 #define L1_DMA DMA_B DMA_C DMA_D DMA_E
