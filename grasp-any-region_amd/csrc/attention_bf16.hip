@@ -165,18 +165,61 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             const char* ks = smem + buf * (KT + VT);
             const char* vs = ks + KT;
             f32x16 s[2];
+            auto qk = [&]() {
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+                for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-                for (int kd = 0; kd < NKD; ++kd) {
-                    const bf16x8 kf =
-                        *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
+                    for (int kd = 0; kd < NKD; ++kd) {
+                        const bf16x8 kf =
+                            *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
+                        s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
+                    }
                 }
-            }
+            };
+            qk();
             TLA(2)
             // register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
             const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
+            float ps = 0.f;
+            bf16x8 pf[2][2];
+            // p = exp2(s - m_sub) (NEGM: s already carries -m), row sum, bf16 pack
+            auto exp_pack = [&](float m_sub) {
+                ps = 0.f;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_sub);
+                        ps += p[r];
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        u32x4 w;
+                        w[0] = cvt_pk(p[tt * 8 + 0], p[tt * 8 + 1]);
+                        w[1] = cvt_pk(p[tt * 8 + 2], p[tt * 8 + 3]);
+                        w[2] = cvt_pk(p[tt * 8 + 4], p[tt * 8 + 5]);
+                        w[3] = cvt_pk(p[tt * 8 + 6], p[tt * 8 + 7]);
+                        pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
+                    }
+                }
+            };
+            // Lazy running max. The max only guards the exponent range: P and the O / l accumulators are rounded
+            // relative to their own magnitude, so measuring a tile's scores against a max that is up to 2^LAZY_LOG2 too
+            // small costs no accuracy. Tile 0 (and every masked tile) takes the exact path below and leaves a finite max
+            // under which the row's l is >= 1; every later tile exponentiates against that max at once — no 32-way max,
+            // no half-row exchange, no compare — and only looks at the row sums it needs anyway: a lane whose partial sum
+            // reaches 2^LAZY_LOG2 (or is inf / NaN) sends the wave through the exact path, which re-bases the max and
+            // redoes the tile from the scores still in registers.
+#ifndef ATTN_LAZY_LOG2
+#define ATTN_LAZY_LOG2 16       /* 0: always the exact path (A/B) */
+#endif
+            bool exact = ATTN_LAZY_LOG2 == 0 || t == 0 || need_mask;                          // wave-uniform
+            if (!exact) {
+                exp_pack(NEGM ? 0.f : m_run);
+                exact = !__all(ps < (float)(1u << ATTN_LAZY_LOG2));
+            }
+            if (exact) {
             if (need_mask) {
                 const int qi = q0 + l31;
                 const int lim = CAUSAL ? min(kv_len - 1, qi + coff) : kv_len - 1;
@@ -230,25 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[r] = -m_nu;
             }
-            float ps = 0.f;
-            bf16x8 pf[2][2];
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                float p[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_use);
-                    ps += p[r];
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    u32x4 w;
-                    w[0] = cvt_pk(p[tt * 8 + 0], p[tt * 8 + 1]);
-                    w[1] = cvt_pk(p[tt * 8 + 2], p[tt * 8 + 3]);
-                    w[2] = cvt_pk(p[tt * 8 + 4], p[tt * 8 + 5]);
-                    w[3] = cvt_pk(p[tt * 8 + 6], p[tt * 8 + 7]);
-                    pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
-                }
+            exp_pack(m_use);
             }
             l_run += ps;
             TLA(4)

@@ -14,7 +14,10 @@ from gar_amd import hip, ops  # noqa: E402
 def main():
     hip.require_device(0)
     dev, dt = "cuda:0", torch.bfloat16
-    for name, B, Hq, Hkv, hd, n, causal in (("vit", 272, 16, 16, 64, 1025, False), ("prefill", 16, 32, 8, 64, 4718, True)):
+    shapes = [("vit", 272, 16, 16, 64, 1025, False), ("prefill", 16, 32, 8, 64, 4718, True)]
+    if os.environ.get("SHAPESET") == "all":      # + GAR-8B: PE-G/14 (head_dim 96, no cls token) and Llama-3.1-8B prefill (head_dim 128)
+        shapes += [("vit 8b", 80, 16, 16, 96, 1024, False), ("prefill 8b", 16, 32, 8, 128, 1590, True)]
+    for name, B, Hq, Hkv, hd, n, causal in shapes:
         npad = (n + 63) // 64 * 64
         Q = torch.randn(B, Hq, npad, hd, device=dev).to(dt) * 0.2
         K = torch.randn(B, Hkv, npad, hd, device=dev).to(dt)
@@ -33,7 +36,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         fl = 4.0 * B * Hq * n * n * hd * (0.5 if causal else 1.0)
-        print(f"{name:8s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        print(f"{name:10s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
