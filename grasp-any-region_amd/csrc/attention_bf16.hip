@@ -123,11 +123,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     float m_run = -INFINITY, l_run = 0.f;
     // The QK^T accumulator chains start from -m (the running max the scores are measured against) instead of 0: the MFMA
     // delivers s - m and the softmax needs no subtraction — 32 VALU instructions fewer per kv tile in a loop whose SIMD
-    // time is (matrix pipe time + VALU issue time), see profiles/r2_attention_timeline.txt. 16 VGPRs, rewritten only
-    // when the max moves by more than 2^RESCALE_THR. Non-causal head_dim 64 (the ViT) only: +2.0 ... +3.4 % there; the
-    // causal instantiation goes from 144 to 201 VGPRs with it (-7 %), and with head_dim 96 / 128 the softmax is half as
-    // large next to the MFMAs while the accumulators leave no room (profiles/r2_attention_experiments.txt).
-    constexpr bool NEGM = HD == 64 && !CAUSAL;
+    // time is matrix pipe time plus most of the VALU issue time (tools/coissue_probe.hip, profiles/r2_attention_timeline.txt).
+    // 16 VGPRs, rewritten only when the max is re-based. With the exact max on every tile this paid for non-causal
+    // head_dim 64 only (the causal instantiation went from 144 to 201 VGPRs: -7 %); with the lazy max below the -m vector
+    // is all but constant and every instantiation gains: causal head_dim 64 +5.4 %, head_dim 128 +4.5 %, 96 +4 %
+    // (same-box A/Bs of -DATTN_NEGM_SET builds, profiles/r2_attention_lazy_max.txt).
+#ifndef ATTN_NEGM_SET       /* bit 0: head_dim 64, bit 1: 128, bit 2: 96 */
+#define ATTN_NEGM_SET 7
+#endif
+    constexpr bool NEGM = (HD == 64 && (ATTN_NEGM_SET & 1)) || (HD == 128 && (ATTN_NEGM_SET & 2)) || (HD == 96 && (ATTN_NEGM_SET & 4));
     f32x16 negm = zero16_c();
 
     int kv_end = kv_len;
