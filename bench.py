@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-patch-gather", action="store_true",
                     help="A/B: patch-embed as gar_patch_im2col + GEMM instead of gar_patch_embed (patches DMA'd from the "
                          "image tiles into LDS)")
+    ap.add_argument("--vit-v-transpose", action="store_true",
+                    help="A/B: ViT v through gar_vit_v_transpose + Vt attention instead of the row-major form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args()
@@ -176,6 +178,8 @@ def main():
         model.prefill_chunk = args.prefill_chunk or None
     if args.no_patch_gather:
         model.w_patch_gather = None
+    if args.vit_v_transpose:
+        model.VIT_V_ROW_MAJOR = False
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")

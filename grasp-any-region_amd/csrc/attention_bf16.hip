@@ -32,7 +32,14 @@ __device__ __forceinline__ f32x16 zero16_c() {
 
 template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
 
-template <int HD, bool CAUSAL>
+// VROW (head_dim 64): V arrives row-major [kv][HD] — the layout the fused qkv GEMM epilogue writes, no transpose pass — is
+// DMA'd like a K tile, and the PV A operand (rows = d, k = kv: column-major in that image) comes out of
+// ds_read_b64_tr_b16, gfx950's transposing LDS read: each 16-lane group reads one [4 kv][16 d] block, lane i supplying
+// the address of the block's chunk (kv row i >> 2, d columns 4 (i & 3) ..) and receiving column i; two reads = the 8
+// consecutive kv of one d that the MFMA fragment wants. The 16-byte chunks of a V row are XOR-ed with 4 ((kv >> 1) & 1):
+// the four rows of a block (128 B apart) then cover all 64 banks exactly once for a 32-lane half.
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     const int coff = kv_len - q_len;            // causal: kv <= q + coff
     const bf16_t* Qp = Q + (((int64_t)b * Hq + head) * q_pad) * HD;
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const bf16_t* Vp = VROW ? Vt + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD
+                            : Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
@@ -87,7 +95,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         const int cl = (lane & 15) ^ key_of<256>(row);                    // logical 16-byte chunk this lane fetches
         voffK = row * KRS_G + (min(cl, KRS_G / 16 - 1) << 4);
     }
-    {
+    if (VROW) {             // V piece = 8 kv rows x 128 B (64 d); chunk key 4 ((row >> 1) & 1)
+        const int row = wave * 8 + (lane >> 3);
+        voffV = row * 128 + (((lane & 7) ^ (((row >> 1) & 1) << 2)) << 4);
+    } else {
         const int row = wave * 8 + (lane >> 3);      // Vt piece = 8 d-rows x 128 B (64 kv)
         voffV = (int)((unsigned)row * (unsigned)kv_stride * 2u) + (((lane & 7) ^ key_of<128>(row)) << 4);
     }
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         char* ks = smem + buf * (KT + VT);
         char* vs = ks + KT;
         const unsigned kbase = (unsigned)t * 64u * KRS_G;               // 64 kv rows per tile
-        const unsigned vbase = (unsigned)t * 128u;                      // 64 kv columns
+        const unsigned vbase = VROW ? (unsigned)t * 64u * 128u : (unsigned)t * 128u;      // 64 kv rows / 64 kv columns
 #pragma unroll
         for (int i = 0; i < KI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
@@ -103,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
         for (int i = 0; i < VI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
-                                                     voffV + (int)(vbase + (unsigned)i * 32u * (unsigned)kv_stride * 2u),
+                                                     voffV + (int)(vbase + (VROW ? (unsigned)i * 32u * 128u
+                                                                                         : (unsigned)i * 32u * (unsigned)kv_stride * 2u)),
                                                      0, 0, 0);
     };
 
@@ -151,6 +163,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         const int row = blk * 32 + prow;
         koff[blk] = row * KRS;
         kkey[blk] = key_of<KRS>(row);
+    }
+    // VROW: byte offset inside a V tile of this lane's tr-read chunk for d-block 0 (d-block 1 = chunk index + 4 = ^ 64 bytes)
+    int vtr = 0;
+    if (VROW) {
+        const int i = lane & 15, r = 8 * h + (i >> 2);                    // kv row inside the 16-kv step
+        const int col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);             // d column inside the 32-d block
+        vtr = r * 128 + ((((col >> 3) ^ (((r >> 1) & 1) << 2)) << 4) | ((col & 7) << 1));
     }
 #ifdef ATTN_TIMELINE
     unsigned tl_t[8], tl_sum[8];
@@ -289,8 +308,20 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const int c = (blk * 2 + tt) * 2 + h;
-                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + ((c ^ key) << 4));
+                        bf16x8 vf;
+                        if (VROW) {
+                            // this lane's chunk of its group's [4 kv][16 d] block: kv row (blk*32 + tt*16 + 8h) + (i >> 2) (+4),
+                            // d columns d*32 + 16 ((lane >> 4) & 1) + 4 (i & 3);  i = lane & 15.  vtr = byte offset of (kv row i >> 2 of
+                            // the wave-tile's row 8h, that d chunk) with the row key of rows 0-1; rows 2-3 flip chunk bit 2
+                            const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16) * 128 + (vtr ^ (d << 6))));
+                            const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16 + 4) * 128 + (vtr ^ (d << 6))));
+                            vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        } else {
+                            const int c = (blk * 2 + tt) * 2 + h;
+                            vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + ((c ^ key) << 4));
+                        }
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[blk][tt], o[d], 0, 0, 0);
                     }
             }
@@ -336,18 +367,23 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     }
 }
 
-// returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip)
+// returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip).
+// vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
-                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, hipStream_t s) {
+                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow, hipStream_t s) {
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
+    if (vrow && hd != 64) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
     const int lds = 2 * (64 * (hd == 64 ? 128 : 256) + hd * 128);
-#define LAUNCH_V2(HD_, C_)                                                                                            \
-    hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,       \
+#define LAUNCH_V2(HD_, C_, V_)                                                                                         \
+    hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
                        (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev)
-    if (hd == 64) { if (causal) LAUNCH_V2(64, true); else LAUNCH_V2(64, false); }
-    else if (hd == 128) { if (causal) LAUNCH_V2(128, true); else LAUNCH_V2(128, false); }
-    else if (hd == 96) { if (causal) LAUNCH_V2(96, true); else LAUNCH_V2(96, false); }
+    if (hd == 64) {
+        if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
+        else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }
+    }
+    else if (hd == 128) { if (causal) LAUNCH_V2(128, true, false); else LAUNCH_V2(128, false, false); }
+    else if (hd == 96) { if (causal) LAUNCH_V2(96, true, false); else LAUNCH_V2(96, false, false); }
     else return false;
 #undef LAUNCH_V2
     return true;

@@ -463,6 +463,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             bf16_t* dst = (bf16_t*)(part == 0 ? p.qkv_q : p.qkv_k) +
                                           (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd;
                             st8(dst, o);
+                        } else if (p.qkv_v) {        // v head-major like k (consumed by gar_attention_vrow: no transpose pass)
+                            st8((bf16_t*)p.qkv_v +
+                                    (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
                         } else {
                             st8((bf16_t*)p.C + (int64_t)m * p.ldc + nn, o);
                         }
@@ -664,6 +667,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                     for (int e = 0; e < 8; ++e) o[e] *= p.qkv_q_scale;
                                 }
                                 st8((bf16_t*)(part == 0 ? p.qkv_q : p.qkv_k) +
+                                        (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
+                            } else if (p.qkv_v) {
+                                st8((bf16_t*)p.qkv_v +
                                         (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
                             } else {
                                 st8((bf16_t*)p.C + (int64_t)m * p.ldc + nn, o);

@@ -94,6 +94,7 @@ def _on_model_device(fn):
 
 
 class GARModel:
+    VIT_V_ROW_MAJOR = True        # bf16, head_dim 64: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
     FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
 
@@ -329,6 +330,8 @@ class GARModel:
         # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
         # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
         fused = self.dtype == torch.bfloat16
+        # head_dim 64 in bf16: V stays row-major [Tt, H, Npad, hd] (zero-initialised like Q / K: pad rows must be finite)
+        Vr = self._buf(key, "Vr", (Tt, H, Npad, hd), zero=True) if fused and hd == 64 and self.VIT_V_ROW_MAJOR else None
         vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         x2 = x.view(Tt * N, D)
@@ -354,13 +357,17 @@ class GARModel:
             ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
             if fused:
                 fused = ops.gemm_qkv_rope(hbuf, blk["qkv_w"], blk["qkv_b"], vrow, Q, K, self.vit_sin, self.vit_cos, H, hd, N,
-                                          Npad, self.npt, q_scale)
-            if fused:
+                                          Npad, self.npt, q_scale, V=Vr)
+            if fused and Vr is None:
                 ops.vit_v_transpose(vrow, Vt, Tt, N, H, hd, Npad)
-            else:
+            elif not fused:
+                Vr = None
                 ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
                 ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
-            ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
+            if Vr is not None:      # v left the qkv GEMM head-major like k: the attention transposes it on its LDS reads
+                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True)
+            else:
+                ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
             ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])
             ops.layernorm(x2, *blk["n2"], v.ln_eps, out=hbuf)
             f1v = f1.view(-1)[:Tt * N * Dm].view(Tt * N, Dm)

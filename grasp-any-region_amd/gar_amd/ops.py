@@ -198,7 +198,7 @@ def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
 
 
 def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale,
-                  compact: bool = True) -> bool:
+                  compact: bool = True, V: Optional[torch.Tensor] = None) -> bool:
     """qkv GEMM with the front half of timm AttentionRope fused (GAR_EPI_QKV_ROPE): q / k are rotated, scaled and written
     straight into Q / K [tiles, heads, tokens_pad, hd]; v goes row-major to ``v_out`` [M, heads*hd]. Returns False when the
     library does not take this shape / dtype on the fused path (caller keeps gemm + vit_qkv_post)."""
@@ -220,6 +220,9 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
         p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sin), ptr(cos)
     p.qkv_heads, p.qkv_head_dim, p.qkv_tokens, p.qkv_tokens_pad, p.qkv_prefix = heads, hd, tokens, tokens_pad, prefix
     p.qkv_q_scale = q_scale
+    # V [tiles, heads, tokens_pad, hd]: v leaves the GEMM head-major like k (attention(..., v_row_major=True) reads it in
+    # place); v_out is then not written
+    p.qkv_v = ptr(V)
     prof = KERNEL_TIMERS
     timed = prof is not None and not torch.cuda.is_current_stream_capturing()
     if timed:
@@ -245,7 +248,13 @@ def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0,
                                  Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), q_scale, stream()), "gar_llm_qkv_post")
 
 
-def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None):
+def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None,
+              v_row_major: bool = False):
+    """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout; bf16, head_dim 64) instead of its transpose."""
+    if v_row_major:
+        check(lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention_vrow")
+        return
     check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
                               kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention")
 

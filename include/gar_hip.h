@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 5
+#define GAR_ABI_VERSION 6
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -51,7 +51,8 @@ extern "C" {
                                   /* m % qkv_tokens of image tile m / qkv_tokens. q, k: interleaved-pair RoPE for   */
                                   /* tokens >= qkv_prefix (tables [tokens - prefix, head_dim] f32), q * qkv_q_scale, */
                                   /* written to qkv_q / qkv_k [tiles, heads, qkv_tokens_pad, head_dim]; v written   */
-                                  /* row-major to C [M, heads*head_dim] (transposed later by gar_vit_v_transpose)   */
+                                  /* row-major to C [M, heads*head_dim] (transposed later by gar_vit_v_transpose),  */
+                                  /* or head-major to qkv_v when that is set (gar_attention_vrow reads it in place)  */
 
 typedef void* gar_stream_t;
 
@@ -86,6 +87,9 @@ typedef struct gar_gemm_params {
      * [split_k][M][N] (C is not written) and gar_splitk_residual_rmsnorm — the launch that follows anyway — sums them.
      * No atomics and no fences: a narrow output (Llama `down`: 128 weight tiles) then streams from 4x the workgroups. */
     int32_t split_k; float* partial;
+    /* GAR_EPI_QKV_ROPE: when not NULL, v goes here head-major [tiles, heads, qkv_tokens_pad, head_dim] — the layout of
+     * qkv_k, consumed by gar_attention_vrow — instead of row-major to C (which then is not written) */
+    void* qkv_v;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -162,6 +166,13 @@ int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* 
 int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd,
                   int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                   gar_stream_t stream);
+/* The same with V row-major, [B,Hkv,kv_stride,hd] like K (what GAR_EPI_QKV_ROPE writes to gar_gemm_params.qkv_v): the PV
+ * operand is formed by gfx950's transposing LDS read (ds_read_b64_tr_b16), so timm AttentionRope's v needs no transpose
+ * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64;
+ * GAR_ERR_UNSUPPORTED (nothing launched) otherwise. */
+int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd,
+                       int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
+                       gar_stream_t stream);
 
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
  * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / Vt.

@@ -362,6 +362,28 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
     ref = _attn_ref(qq, kk, vv, False, 0).transpose(1, 2).reshape(T * N, D)
     close(out, ref, dt, extra=2.0)
     assert torch.isfinite(out.float()).all()
+    if dt == torch.bfloat16 and hd == 64:
+        # V row-major [T, H, Npad, hd] (what the fused qkv GEMM writes), transposed by the attention's LDS reads
+        # (ds_read_b64_tr_b16): same P, same V, same MFMA order -> bit-identical to the Vt form. Pad rows hold large
+        # finite values: they meet P = 0 only.
+        Vr = torch.full((T, H, Npad, hd), 1e4, dtype=dt, device=dev)
+        Vr[:, :, :N] = Vt.transpose(2, 3)[:, :, :N]
+        out2 = torch.empty_like(out)
+        ops.attention(Q, K, Vr, out2, T, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True)
+        assert torch.equal(out2, out)
+        outc, outc2 = torch.empty_like(out), torch.empty_like(out)
+        ops.attention(Q, K, Vt, outc, T, H, H, hd, N, Npad, N, Npad, causal=True)
+        ops.attention(Q, K, Vr, outc2, T, H, H, hd, N, Npad, N, Npad, causal=True, v_row_major=True)
+        assert torch.equal(outc2, outc)
+
+
+def test_attention_vrow_refuses_other_head_dims(dev):
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    Q = torch.zeros(1, 1, 64, 128, dtype=dt, device=dev)
+    with pytest.raises(hip.GarError):
+        ops.attention(Q, Q, Q, torch.zeros(64, 128, dtype=dt, device=dev), 1, 1, 1, 128, 64, 64, 64, 64, causal=False,
+                      v_row_major=True)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -810,3 +832,12 @@ def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact
     if Npad > N:
         assert float(Q1[:, :, N:].abs().max()) == 0 and float(K1[:, :, N:].abs().max()) == 0
         assert float(V1[:, :, :, N:].abs().max()) == 0
+    # v written head-major by the epilogue itself (gar_gemm_params.qkv_v): the same values, [T, H, Npad, hd]; the
+    # row-major output is then left alone
+    Q2, K2 = (torch.zeros(T, H, Npad, hd, dtype=dt, device=dev) for _ in range(2))
+    V2 = torch.zeros(T, H, Npad, hd, dtype=dt, device=dev)
+    vrow2 = torch.full((T * N, D), 3.0, dtype=dt, device=dev)
+    assert ops.gemm_qkv_rope(a, w, b, vrow2, Q2, K2, sin, cos, H, hd, N, Npad, npt, qs, compact=compact, V=V2)
+    assert torch.equal(Q2, Q1) and torch.equal(K2, K1)
+    assert torch.equal(V2[:, :, :N], V1.transpose(2, 3)[:, :, :N])
+    assert float((vrow2 - 3.0).abs().max()) == 0 and (Npad == N or float(V2[:, :, N:].abs().max()) == 0)

@@ -24,8 +24,14 @@ def main():
         Vt = torch.randn(B, Hkv, hd, npad, device=dev).to(dt)
         O = torch.empty(B * n, Hq * hd, device=dev, dtype=dt)
 
+        vrow = os.environ.get("VROW") == "1" and hd == 64
+        Vr = Vt.transpose(2, 3).contiguous() if vrow else None
+
         def run():
-            ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
+            if vrow:
+                ops.attention(Q, K, Vr, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal, v_row_major=True)
+            else:
+                ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
