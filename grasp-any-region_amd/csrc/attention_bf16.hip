@@ -39,6 +39,9 @@ template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 
 // consecutive kv of one d that the MFMA fragment wants. The 16-byte chunks of a V row are XOR-ed with 4 ((kv >> 1) & 1):
 // the four rows of a block (128 B apart) then cover all 64 banks exactly once for a 32-lane half.
 typedef short tr4_t __attribute__((ext_vector_type(4)));
+#ifndef ATTN_MFMA_ROWSUM   /* 1: row sums of P on the matrix pipe (ones x P), instead of 32 VALU adds per tile and lane */
+#define ATTN_MFMA_ROWSUM 0
+#endif
 template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_sub);
-                        ps += p[r];
+                        if (!ATTN_MFMA_ROWSUM) ps += p[r];
                     }
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
@@ -225,6 +228,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                         w[3] = cvt_pk(p[tt * 8 + 6], p[tt * 8 + 7]);
                         pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
                     }
+                }
+                if (ATTN_MFMA_ROWSUM) {
+                    // ones[32 x 16] x P[16 kv x 32 q], four k-steps: every register of the result is the COMPLETE row sum of
+                    // this lane's query column (both kv halves) of the bf16-rounded P — what the PV product divides by
+                    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+                    f32x16 ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[0][0], zero16, 0, 0, 0);
+                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[0][1], ls, 0, 0, 0);
+                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[1][0], ls, 0, 0, 0);
+                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[1][1], ls, 0, 0, 0);
+                    ps = ls[0];
                 }
             };
             // Lazy running max. The max only guards the exponent range: P and the O / l accumulators are rounded
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     }
 #endif
     // epilogue: O[b*q_len + q][head*HD + d], d = 32 db + (r&3) + 8 (r>>2) + 4 h
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = ATTN_MFMA_ROWSUM ? l_run : l_run + __shfl_xor(l_run, 32, 64);
     const int qi = q0 + l31;
     if (qi < q_len) {
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;

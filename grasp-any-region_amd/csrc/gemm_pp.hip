@@ -88,13 +88,14 @@ __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsi
 // (1/128)^2 / 8 * 0.8 = 6e-6 (bf16 rounds at 4e-3 relative), 9 VALU + one ds_read_b64 per element. x >= 8 returns x.
 #define GELU_LUT_N 2048
 #define GELU_LUT_BYTES (GELU_LUT_N * 8)
+// Only the interval INDEX is clamped, not the interpolation weight: beyond the table the last / first interval is
+// extended linearly — gelu(x) = x to fp32 precision for x >= 8 (the last interval's slope is 1) and 0 for x <= -8 (the
+// first entry's slope is stored as 0) — so there is no range test: 7 VALU + one ds_read_b64 per element (9 with one).
 __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
     const float u = __builtin_fmaf(x, 128.0f, 1024.0f);
-    const float uc = __builtin_amdgcn_fmed3f(u, 0.0f, 2047.99f);
-    const float fi = __builtin_floorf(uc);
+    const float fi = __builtin_floorf(__builtin_amdgcn_fmed3f(u, 0.0f, 2047.0f));
     const float2 e = *reinterpret_cast<const float2*>(lut + ((int)fi << 3));
-    const float y = __builtin_fmaf(e.y, uc - fi, e.x);
-    return x >= 8.0f ? x : y;
+    return __builtin_fmaf(e.y, u - fi, e.x);
 }
 
 // Patch gather (GATHER, GAR_EPI_PATCH_POS only — gar_patch_embed): the A operand is not a matrix in HBM but the image
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             const int k = tid + 512 * j;
             const float x0 = -8.0f + (float)k * (1.0f / 128.0f);
             const float g0 = gelu_erf(x0), g1 = gelu_erf(x0 + 1.0f / 128.0f);
-            *reinterpret_cast<float2*>(smem + 2 * PSTAGE + k * 8) = make_float2(g0, g1 - g0);
+            // slopes are per table step; entry 0 extends to x < -8 with slope 0, entry 2047 to x > 8 with slope 1 / 128 per step
+            *reinterpret_cast<float2*>(smem + 2 * PSTAGE + k * 8) =
+                make_float2(g0, k == 0 ? 0.0f : (k == GELU_LUT_N - 1 ? (x0 + 1.0f / 128.0f) - g0 : g1 - g0));
         }
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -77,6 +77,13 @@ def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
     bias, gamma, res = q(rnd(N, seed=52), dt), q(rnd(N, seed=53), dt), q(rnd(M, N, seed=54), dt)
     ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=bias.to(dev, dt))
     close(out, F.gelu(acc + bias.double()), dt)
+    # the GELU table's ends: inputs far outside [-8, 8) (|x| up to ~40) must come out as x resp. 0, to bf16 rounding of
+    # the VALUE (not of the table's range) — the table extends its last / first interval instead of testing the range
+    wide = q(rnd(N, seed=55) * 12.0, dt)
+    ops.gemm(A, W_, out, hip.EPI_BIAS_GELU, bias=wide.to(dev, dt))
+    refw = F.gelu(acc + wide.double())
+    errw = (out.float().cpu().double() - refw).abs()
+    assert float((errw - 2.0 ** -8 * refw.abs()).max()) <= 1e-5, float(errw.max())
     ops.gemm(A, W_, out, hip.EPI_BIAS, bias=bias.to(dev, dt))
     close(out, acc + bias.double(), dt)
     r = res.to(dev, dt).clone()
