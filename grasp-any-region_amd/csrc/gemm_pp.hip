@@ -513,10 +513,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
         // destination element offset and row-dependent load of row-side slot (i, t)
         auto row_of = [&](int i, int t) { return m0 + wm * 128 + i * 16 + t * 8 + rr; };
+        // (image tile, token) of row m for the epilogues that address by token (PATCH_POS, QKV_ROPE). The 128 rows of a
+        // wave's strip are consecutive and span at most two image tiles when a tile has >= 128 tokens: ONE integer division
+        // per strip and a compare / select per row instead of a ~25-instruction division per row (32 per lane and tile —
+        // as many VALU instructions as the rest of the QKV_ROPE epilogue)
+        const int TT = EPI == GAR_EPI_QKV_ROPE ? p.qkv_tokens : (EPI == GAR_EPI_PATCH_POS ? p.tokens_in : 1);
+        const int mw = m0 + wm * 128;
+        const int tile_w = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_PATCH_POS) ? mw / TT : 0;
+        const int tok_w = mw - tile_w * TT;
+        auto split_row = [&](int m, int& tile, int& tok) {
+            if (TT >= 128) {
+                tok = tok_w + (m - mw);
+                const bool wrap = tok >= TT;
+                tile = tile_w + (wrap ? 1 : 0);
+                tok -= wrap ? TT : 0;
+            } else {
+                tile = m / TT;
+                tok = m - tile * TT;
+            }
+        };
         auto dst_off = [&](int m) -> int64_t {
             if (EPI == GAR_EPI_PATCH_POS) {
-                const int tile = m / p.tokens_in;
-                return ((int64_t)tile * p.tokens_out + p.token_offset + (m - tile * p.tokens_in)) * p.ldc + n;
+                int tile, tok;
+                split_row(m, tile, tok);
+                return ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
             }
             if (PP_DIAG_L2STORE) return (int64_t)(m - m0) * p.ldc + (n - n0);     // diagnostic build: L2-resident stores
             return (int64_t)m * p.ldc + n;
@@ -524,8 +544,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional (clamped) so the prefetch ring carries no exec state
             const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
             if (EPI == GAR_EPI_PATCH_POS) {
-                const int tile = m / p.tokens_in;
-                const int tok = p.token_offset + (m - tile * p.tokens_in);
+                int tile, tk;
+                split_row(m, tile, tk);
+                const int tok = p.token_offset + max(tk, 0);
                 return *reinterpret_cast<const u32x4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + nc);
             }
             return *reinterpret_cast<const u32x4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + nc);
@@ -538,7 +559,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
         auto sc_load = [&](int i, int t, int half) -> u32x4 {
             const int m = min(row_of(i, t), p.M - 1);
-            const int tok = m - (m / p.qkv_tokens) * p.qkv_tokens;
+            int tile, tok;
+            split_row(m, tile, tok);
             const int rt = max(tok - p.qkv_prefix, 0);
             return *reinterpret_cast<const u32x4*>(p.qkv_sin + ((int64_t)rt * p.qkv_head_dim + (nok && part < 2 ? qd : 0)) + half * 4);
         };
@@ -653,7 +675,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             }
                         }
                         if (QKV) {
-                            const int tile = m / p.qkv_tokens, tok = m - tile * p.qkv_tokens;
+                            int tile, tok;
+                            split_row(m, tile, tok);
                             if (part < 2) {
                                 if (tok >= p.qkv_prefix) {      // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs
 #pragma unroll

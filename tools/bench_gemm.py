@@ -22,7 +22,7 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
           ("qkv none", 139400, 3072, 1024, hip.EPI_NONE), ("llm o none", 37744, 2048, 2048, hip.EPI_NONE)]
 
 # the planner's passes (gar_amd/planner.py, bench default): 387 image tiles x 1025 tokens, 26 sequences x 4718 tokens
-PLAN_SHAPES = [("vit qkv", 396675, 3072, 1024, hip.EPI_BIAS), ("vit proj", 396675, 1024, 1024, hip.EPI_BIAS_SCALE_RES),
+PLAN_SHAPES = [("vit qkv rope", 396675, 3072, 1024, hip.EPI_QKV_ROPE), ("vit qkv", 396675, 3072, 1024, hip.EPI_BIAS), ("vit proj", 396675, 1024, 1024, hip.EPI_BIAS_SCALE_RES),
                ("vit fc1", 396675, 4096, 1024, hip.EPI_BIAS_GELU), ("vit fc2", 396675, 1024, 4096, hip.EPI_BIAS_SCALE_RES),
                ("llm qkv", 122668, 3072, 2048, hip.EPI_NONE), ("llm o", 122668, 2048, 2048, hip.EPI_RES),
                ("llm gate/up", 122668, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 122668, 2048, 8192, hip.EPI_RES)]
@@ -43,18 +43,29 @@ def main():
         No = N // 2 if epi == hip.EPI_SWIGLU else N
         out = torch.empty(M, No + pad_c, device=dev, dtype=torch.bfloat16)[:, :No]
         kw = {}
-        if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES):
+        if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES, hip.EPI_QKV_ROPE):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
         if epi in (hip.EPI_BIAS_SCALE_RES, hip.EPI_RES):
             kw["residual"] = out
         if epi == hip.EPI_BIAS_SCALE_RES:
             kw["gamma"] = torch.randn(N, device=dev).to(torch.bfloat16)
+        if epi == hip.EPI_QKV_ROPE:         # the fused ViT qkv GEMM: 16 heads x 64, 1025 tokens per image tile (1 cls), v head-major
+            H, hd, T = 16, 64, M // 1025
+            Q_, K_, V_ = (torch.zeros(T, H, 1088, hd, device=dev, dtype=torch.bfloat16) for _ in range(3))
+            ang = torch.randn(1024, hd // 2, device=dev)
+            sin, cos = (f(ang).repeat_interleave(2, -1).contiguous() for f in (torch.sin, torch.cos))
+
+            def call():
+                assert ops.gemm_qkv_rope(a, w, kw["bias"], out, Q_, K_, sin, cos, H, hd, 1025, 1088, 1, 0.18, V=V_)
+        else:
+            def call():
+                ops.gemm(a, w, out, epi, **kw)
         for _ in range(2):
-            ops.gemm(a, w, out, epi, **kw)
+            call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.gemm(a, w, out, epi, **kw)
+            call()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps

@@ -53,7 +53,9 @@ def main(fetch_csv, write_csv, out_json, read_scale=None):
         calib["WRITE_SIZE/expected(8B-per-lane writes)"] = wr[k][1] / (8.0 * wr[k][2])
     # our own streaming kernel with a known byte count: vit_qkv_post reads each qkv element once and writes it once
     # (16-B/lane loads and stores), so FETCH_SIZE / WRITE_SIZE should be 1.0 — 0.5 means FETCH_SIZE under-counts x2
-    for k2 in ("vit_qkv_post_kernel", "vit_v_transpose_kernel"):     # streaming relayout kernels: reads == writes
+    # streaming kernels that read every element once and write it once with 16-byte accesses: reads == writes
+    # (vit_v_transpose left the bf16 head_dim-64 path in round 2; mask_decode / llm_qkv_post are always there)
+    for k2 in ("vit_qkv_post_kernel", "vit_v_transpose_kernel", "mask_decode_kernel", "llm_qkv_post_kernel"):
         if k2 in rd and k2 in wr and wr[k2][1] > 0:
             calib[f"FETCH_SIZE/WRITE_SIZE({k2}: reads == writes)"] = rd[k2][1] / wr[k2][1]
     scale = float(read_scale) if read_scale is not None else 1.0
