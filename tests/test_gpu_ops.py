@@ -384,6 +384,53 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
         assert torch.equal(outc2, outc)
 
 
+@pytest.mark.parametrize("hd", [64, 96, 128])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("profile", ["rising", "spike", "falling", "huge"])
+def test_attention_lazy_max_redo_path(dev, hd, causal, profile):
+    """The bf16 attention exponentiates every tile after the first against the STANDING running max and only checks the
+    row sums (attention_bf16.hip, lazy running max); a tile whose scores outgrow that max by more than 2^16 must send the
+    wave through the exact path (re-base, redo). Score profiles that force it: keys whose magnitude rises tile by tile,
+    one spike tile in the middle, and a fall (the cheap path all the way, with p underflowing to 0); 'huge' jumps by
+    more than 2^128 in one tile (exp2 overflows to inf on the lazy pass: the check must still catch it)."""
+    from gar_amd import ops
+    dt = torch.bfloat16
+    B, H, n = 1, 2, 64 * 9
+    g = torch.Generator().manual_seed(77)
+    Qf = torch.randn(B, H, n, hd, generator=g)
+    Kf = torch.randn(B, H, n, hd, generator=g)
+    Vf = torch.randn(B, H, n, hd, generator=g)
+    tile = torch.arange(n) // 64
+    scale = {"rising": 1.0 + 8.0 * tile.float(), "spike": torch.where(tile == 4, 70.0, 1.0) * torch.ones(n),
+             "falling": 30.0 / (1.0 + 4.0 * tile.float()), "huge": torch.where(tile >= 5, 400.0, 1.0) * torch.ones(n)}[profile]
+    # every query has a component 4 along a common unit vector u and the keys of a tile are scale * u (+ noise): the
+    # log2-domain scores of a tile are ~ 0.72 * scale * (8 / sqrt(hd)) for every row
+    u = torch.nn.functional.normalize(torch.randn(hd, generator=g), dim=0)
+    Qf = Qf + 4.0 * u
+    Kf = Kf * 0.1 + (hd / 64) ** 0.5 * scale[None, None, :, None] * u
+    qs = hd ** -0.5 * 1.4426950408889634
+    Q = q(Qf * qs, dt).to(dev, dt)
+    K = q(Kf, dt).to(dev, dt)
+    Vt = q(Vf, dt).transpose(2, 3).contiguous().to(dev, dt)
+    out = torch.empty(B * n, H * hd, dtype=dt, device=dev)
+    ops.attention(Q, K, Vt, out, B, H, H, hd, n, n, n, n, causal=causal)
+    s = (Q.double().cpu() @ K.double().cpu().transpose(-1, -2)) * 0.6931471805599453       # Q carries scale * log2(e)
+    if causal:
+        s = s.masked_fill(~torch.ones(n, n, dtype=torch.bool).tril(), float("-inf"))
+    ref = (torch.softmax(s, -1) @ Vt.double().cpu().transpose(2, 3)).transpose(1, 2).reshape(B * n, H * hd)
+    if profile != "falling" and not causal:
+        # the profile does what it is for: past tile 0 the row maxima outgrow the first tile's by more than 2^16
+        s2 = s * 1.4426950408889634
+        growth = s2[..., 64:].max(-1).values - s2[..., :64].max(-1).values
+        assert float(growth.median()) > 20.0 and float((growth > 17.0).float().mean()) > 0.9, float(growth.median())
+    assert torch.isfinite(out.float()).all()
+    close(out, ref, dt, extra=2.0)
+    if hd == 64:
+        out2 = torch.empty_like(out)
+        ops.attention(Q, K, Vt.transpose(2, 3).contiguous(), out2, B, H, H, hd, n, n, n, n, causal=causal, v_row_major=True)
+        assert torch.equal(out2, out)
+
+
 def test_attention_vrow_refuses_other_head_dims(dev):
     from gar_amd import hip, ops
     dt = torch.bfloat16
