@@ -13,6 +13,10 @@
 #include "gemm_epilogue.h"
 
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#ifndef SKINNY_WD_NARROW        /* weight-ring depth of the staged path for NT <= 2 (1 = re-arm one step at a time) */
+#define SKINNY_WD_NARROW 4
+#endif
+#define SKINNY_WD(NT_) ((NT_) <= 2 ? SKINNY_WD_NARROW : 1)
 
 // STAGED: every wave brings the [16 x 64] bf16 tiles of a K step (NT weight tiles + MT activation tiles, 2 KiB each)
 // into a private LDS region with `buffer_load_dwordx4 ... lds` — whole 128-byte row segments, 8 rows per instruction —
@@ -59,8 +63,15 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
     for (int mt = 0; mt < MT; ++mt) ssq[mt] = 0.f;
 
     // ---- STAGED path: DMA tiles -> LDS -> fragments
-    constexpr int REG = (NT + MT) * 2048;
+    // The weight tiles of the next WD - 1 K steps are in flight while a step computes (narrow weight tiles, NT <= 2): a
+    // decode GEMM streams COLD weights — 2.47 GB per token against a 256 MB Infinity Cache — so a wave that re-arms one
+    // step at a time pays one HBM latency (2-3 us under load) per K step: qkv / o ran 11.6 us inside the decode step
+    // against 6.4 us in the micro-benchmark, whose weights stay cache-resident. The activation tiles (L2-resident, the
+    // same for every block) keep one slot.
+    constexpr int WD = SKINNY_WD(NT);
+    constexpr int REG = (WD * NT + MT) * 2048;
     char* wreg = smem + wave * REG;
+    char* xreg = wreg + WD * NT * 2048;
     const unsigned rbW = (unsigned)p.ldw * 2u, rbX = (unsigned)p.lda * 2u;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)W, 0, (int)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
@@ -74,43 +85,57 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
         voffW[i] = (int)((unsigned)(n0 + row) * rbW) + c;
         voffX[i] = (int)((unsigned)row * rbX) + c;
     }
-    auto stage = [&](int ks) {
+    auto stage_w = [&](int ks) {
         const unsigned k0b = (unsigned)ks * 128u;
+        char* slot = wreg + ((ks - ks0) % WD) * (NT * 2048);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(wreg + t * 2048 + i * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(slot + t * 2048 + i * 1024), 16,
                                                          voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, 0);
+    };
+    auto stage_x = [&](int ks) {
+        const unsigned k0b = (unsigned)ks * 128u;
 #ifndef SK_NOX   /* -DSK_NOX: diagnostic build that never stages the activation tiles (wrong results): what the weight
                     stream alone costs (tools/build_variant.sh, profiles/r2_decode_gemm_experiment.txt) */
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_AS(wreg + (NT + mt) * 2048 + i * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_AS(xreg + mt * 2048 + i * 1024), 16,
                                                          voffX[i] + (int)((unsigned)(mt * 16) * rbX + k0b), 0, 0, 0);
 #endif
     };
     const int foff0 = frow * 128 + (((2 * fq) ^ ((frow >> 1) & 7)) << 4);
     const int foff1 = frow * 128 + (((2 * fq + 1) ^ ((frow >> 1) & 7)) << 4);
+    // issue order: W(ks0), X(ks0), W(ks0+1 .. ks0+WD-1) | per step ks: [wait] X(ks+1), W(ks+WD). vmcnt retires in order, so
+    // "all but my newest 2 NT" = everything up to X(ks) has landed — W(ks), issued WD - 1 steps earlier, with it — and the
+    // newest weight step stays in flight; the last steps (nothing newer issued behind X) wait for everything.
     auto step_staged = [&](int ks, bool more) {
         const int k0 = ks * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WD > 1 && ks + WD - 1 < ks1 && ks > ks0) {
+            if (NT == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = wreg + ((ks - ks0) % WD) * (NT * 2048);
         bf16x8 w0[NT], w1[NT], xr0[MT], xr1[MT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            w0[t] = *reinterpret_cast<const bf16x8*>(wreg + t * 2048 + foff0);
-            w1[t] = *reinterpret_cast<const bf16x8*>(wreg + t * 2048 + foff1);
+            w0[t] = *reinterpret_cast<const bf16x8*>(slot + t * 2048 + foff0);
+            w1[t] = *reinterpret_cast<const bf16x8*>(slot + t * 2048 + foff1);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            xr0[mt] = *reinterpret_cast<const bf16x8*>(wreg + (NT + mt) * 2048 + foff0);
-            xr1[mt] = *reinterpret_cast<const bf16x8*>(wreg + (NT + mt) * 2048 + foff1);
+            xr0[mt] = *reinterpret_cast<const bf16x8*>(xreg + mt * 2048 + foff0);
+            xr1[mt] = *reinterpret_cast<const bf16x8*>(xreg + mt * 2048 + foff1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage(ks + 1);                 // re-arm the region: its fragments are in registers now
+        if (more) stage_x(ks + 1);               // re-arm: the fragments of this step are in registers now
+        if (ks + WD < ks1) stage_w(ks + WD);
         __builtin_amdgcn_sched_barrier(0);
         float ga[8], gb[8];
         if (NORM) {
@@ -184,7 +209,13 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
     };
     int ks = ks0;
     if (STAGED) {
-        if (ks < ks1) stage(ks);
+        if (ks < ks1) {
+            stage_w(ks);
+            stage_x(ks);
+#pragma unroll
+            for (int d = 1; d < WD; ++d)
+                if (ks + d < ks1) stage_w(ks + d);
+        }
         for (; ks < ks1; ++ks) step_staged(ks, ks + 1 < ks1);
         __syncthreads();                          // the merge buffer below aliases the staging regions
     } else {
@@ -288,7 +319,7 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     // per-wave staging regions it aliases) <= 136 KiB
     auto lds_for = [&](int w) {
         const int merge = w * NT * MT * 1024 + w * MT * 64;
-        const int stg = staged ? w * (NT + MT) * 2048 : 0;
+        const int stg = staged ? w * (SKINNY_WD(NT) * NT + MT) * 2048 : 0;
         return merge > stg ? merge : stg;
     };
     int nw = 4;

@@ -21,8 +21,13 @@ def main():
     for M in (int(a) for a in (sys.argv[1:] or ["16", "64"])):
         tot = 0.0
         for name, N, K, epi in SHAPES:
-            # L distinct weight matrices so the stream comes from HBM, not from the Infinity Cache
-            ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(L if N < 100000 else 2)]
+            # L distinct weight matrices; COLD=1: as many as it takes to stream >= 1.5 GB per round, so that NO shape is
+            # served by the 256 MB Infinity Cache (16 x qkv = 200 MB and 16 x o = 134 MB are: inside the decode step, where
+            # 2.47 GB of weights pass per token, they are not)
+            nl = L if N < 100000 else 2
+            if os.environ.get("COLD") == "1":
+                nl = max(nl, -(-1_500_000_000 // (N * K * 2)))
+            ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(nl)]
             a = torch.randn(M, K, device=dev).to(torch.bfloat16)
             out = torch.zeros(M, N // 2 if epi == hip.EPI_SWIGLU else N, device=dev, dtype=torch.bfloat16)
             kw = {"residual": out} if epi == hip.EPI_RES else {}
