@@ -412,7 +412,7 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
 
 // Same attention with V row-major [B, Hkv, kv_stride, hd] — the layout K has, and the one the fused qkv GEMM epilogue
 // writes (gar_gemm_params.qkv_v) — read through the transposing LDS load of gfx950: no transpose pass over V.
-// bf16, head_dim 64; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
+// bf16, head_dim 64 / 96 / 128; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
 extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
                                   int hd, int q_len, int q_pad, int kv_len, int kv_stride, int causal,
                                   const int32_t* kv_len_dev, gar_stream_t stream) {
@@ -421,10 +421,10 @@ extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const
     GAR_CHECK_ARG(q_len > 0 && q_pad >= q_len && kv_stride % 64 == 0, "attention_vrow: bad lengths");
     GAR_CHECK_ARG(kv_len_dev || (kv_len > 0 && kv_len <= kv_stride && (!causal || kv_len >= q_len)),
                   "attention_vrow: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
-    if (dtype != GAR_BF16 || hd != 64 ||
+    if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
         !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1,
                               (hipStream_t)stream)) {
-        gar_set_error("attention_vrow: built for bf16, head_dim 64 (dtype %d, head_dim %d)", dtype, hd);
+        gar_set_error("attention_vrow: built for bf16, head_dim 64 / 96 / 128 (dtype %d, head_dim %d)", dtype, hd);
         return GAR_ERR_UNSUPPORTED;
     }
     GAR_CHECK_LAUNCH();

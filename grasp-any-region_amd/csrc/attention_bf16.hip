@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x16 zero16_c() {
 
 template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
 
-// VROW (head_dim 64): V arrives row-major [kv][HD] — the layout the fused qkv GEMM epilogue writes, no transpose pass — is
+// VROW: V arrives row-major [kv][HD] — the layout the fused qkv GEMM epilogue writes, no transpose pass — is
 // DMA'd like a K tile, and the PV A operand (rows = d, k = kv: column-major in that image) comes out of
 // ds_read_b64_tr_b16, gfx950's transposing LDS read: each 16-lane group reads one [4 kv][16 d] block, lane i supplying
 // the address of the block's chunk (kv row i >> 2, d columns 4 (i & 3) ..) and receiving column i; two reads = the 8
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     constexpr int KRS_G = HD * 2;               // K row bytes in HBM
     constexpr int KRS = HD == 64 ? 128 : 256;   // K row bytes in LDS
     constexpr int KT = 64 * KRS;                // K tile bytes in LDS   [64 kv][KRS / 2]
-    constexpr int VT = HD * 128;                // Vt tile bytes  [HD][64 kv]
+    constexpr int VT = VROW ? KT : HD * 128;    // Vt tile bytes [HD][64 kv]; VROW: a V tile has the shape and LDS pitch of a K tile
     constexpr int NKD = HD / 16;                // QK^T k-steps
     constexpr int NDB = HD / 32;                // O^T row blocks
     constexpr int KI = KT / 4096;               // K DMA instructions per wave per tile (1 KiB each)
@@ -98,9 +98,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         const int cl = (lane & 15) ^ key_of<256>(row);                    // logical 16-byte chunk this lane fetches
         voffK = row * KRS_G + (min(cl, KRS_G / 16 - 1) << 4);
     }
-    if (VROW) {             // V piece = 8 kv rows x 128 B (64 d); chunk key 4 ((row >> 1) & 1)
+    if (VROW && HD == 64) { // V piece = 8 kv rows x 128 B (64 d); chunk key 4 ((row >> 1) & 1)
         const int row = wave * 8 + (lane >> 3);
         voffV = row * 128 + (((lane & 7) ^ (((row >> 1) & 1) << 2)) << 4);
+    } else if (VROW) {      // V piece = 4 kv rows x 256 B of LDS (like K); chunk key 4 (row & 3): the four rows of a tr block
+        const int row = wave * 4 + (lane >> 4);                          // are 256 B apart and take the four 64-byte bank groups
+        const int cl = (lane & 15) ^ ((row & 3) << 2);
+        voffV = row * KRS_G + (min(cl, KRS_G / 16 - 1) << 4);
     } else {
         const int row = wave * 8 + (lane >> 3);      // Vt piece = 8 d-rows x 128 B (64 kv)
         voffV = (int)((unsigned)row * (unsigned)kv_stride * 2u) + (((lane & 7) ^ key_of<128>(row)) << 4);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         char* ks = smem + buf * (KT + VT);
         char* vs = ks + KT;
         const unsigned kbase = (unsigned)t * 64u * KRS_G;               // 64 kv rows per tile
-        const unsigned vbase = VROW ? (unsigned)t * 64u * 128u : (unsigned)t * 128u;      // 64 kv rows / 64 kv columns
+        const unsigned vbase = VROW ? (unsigned)t * 64u * KRS_G : (unsigned)t * 128u;     // 64 kv rows / 64 kv columns
 #pragma unroll
         for (int i = 0; i < KI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
         for (int i = 0; i < VI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
-                                                     voffV + (int)(vbase + (VROW ? (unsigned)i * 32u * 128u
+                                                     voffV + (int)(vbase + (VROW ? (unsigned)i * (4096u / KRS) * KRS_G
                                                                                          : (unsigned)i * 32u * (unsigned)kv_stride * 2u)),
                                                      0, 0, 0);
     };
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     if (VROW) {
         const int i = lane & 15, r = 8 * h + (i >> 2);                    // kv row inside the 16-kv step
         const int col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);             // d column inside the 32-d block
-        vtr = r * 128 + ((((col >> 3) ^ (((r >> 1) & 1) << 2)) << 4) | ((col & 7) << 1));
+        const int key4 = HD == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2;
+        vtr = r * KRS + ((((col >> 3) ^ key4) << 4) | ((col & 7) << 1));
     }
 #ifdef ATTN_TIMELINE
     unsigned tl_t[8], tl_sum[8];
@@ -327,9 +332,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                             // d columns d*32 + 16 ((lane >> 4) & 1) + 4 (i & 3);  i = lane & 15.  vtr = byte offset of (kv row i >> 2 of
                             // the wave-tile's row 8h, that d chunk) with the row key of rows 0-1; rows 2-3 flip chunk bit 2
                             const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16) * 128 + (vtr ^ (d << 6))));
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16) * KRS + (vtr ^ (d << 6))));
                             const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16 + 4) * 128 + (vtr ^ (d << 6))));
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16 + 4) * KRS + (vtr ^ (d << 6))));
                             vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         } else {
                             const int c = (blk * 2 + tt) * 2 + h;
@@ -385,9 +390,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow, hipStream_t s) {
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
-    if (vrow && hd != 64) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
-    const int lds = 2 * (64 * (hd == 64 ? 128 : 256) + hd * 128);
+    const int kt = 64 * (hd == 64 ? 128 : 256);
+    const int lds = 2 * (kt + (vrow ? kt : hd * 128));
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
                        (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev)
@@ -395,8 +400,13 @@ bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O,
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }
     }
-    else if (hd == 128) { if (causal) LAUNCH_V2(128, true, false); else LAUNCH_V2(128, false, false); }
-    else if (hd == 96) { if (causal) LAUNCH_V2(96, true, false); else LAUNCH_V2(96, false, false); }
+    else if (hd == 128) {
+        if (vrow) { if (causal) LAUNCH_V2(128, true, true); else LAUNCH_V2(128, false, true); }
+        else { if (causal) LAUNCH_V2(128, true, false); else LAUNCH_V2(128, false, false); }
+    } else if (hd == 96) {
+        if (vrow) { if (causal) LAUNCH_V2(96, true, true); else LAUNCH_V2(96, false, true); }
+        else { if (causal) LAUNCH_V2(96, true, false); else LAUNCH_V2(96, false, false); }
+    }
     else return false;
 #undef LAUNCH_V2
     return true;

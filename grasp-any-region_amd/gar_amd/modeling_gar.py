@@ -94,7 +94,7 @@ def _on_model_device(fn):
 
 
 class GARModel:
-    VIT_V_ROW_MAJOR = True        # bf16, head_dim 64: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
+    VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
     FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
 
@@ -330,8 +330,8 @@ class GARModel:
         # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
         # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
         fused = self.dtype == torch.bfloat16
-        # head_dim 64 in bf16: V stays row-major [Tt, H, Npad, hd] (zero-initialised like Q / K: pad rows must be finite)
-        Vr = self._buf(key, "Vr", (Tt, H, Npad, hd), zero=True) if fused and hd == 64 and self.VIT_V_ROW_MAJOR else None
+        # bf16: V stays row-major [Tt, H, Npad, hd] (zero-initialised like Q / K: pad rows must be finite)
+        Vr = self._buf(key, "Vr", (Tt, H, Npad, hd), zero=True) if fused and self.VIT_V_ROW_MAJOR else None
         vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         x2 = x.view(Tt * N, D)

@@ -168,7 +168,8 @@ int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void*
                   gar_stream_t stream);
 /* The same with V row-major, [B,Hkv,kv_stride,hd] like K (what GAR_EPI_QKV_ROPE writes to gar_gemm_params.qkv_v): the PV
  * operand is formed by gfx950's transposing LDS read (ds_read_b64_tr_b16), so timm AttentionRope's v needs no transpose
- * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64;
+ * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64 /
+ * 96 / 128;
  * GAR_ERR_UNSUPPORTED (nothing launched) otherwise. */
 int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd,
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,

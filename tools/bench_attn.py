@@ -24,7 +24,7 @@ def main():
         Vt = torch.randn(B, Hkv, hd, npad, device=dev).to(dt)
         O = torch.empty(B * n, Hq * hd, device=dev, dtype=dt)
 
-        vrow = os.environ.get("VROW") == "1" and hd == 64
+        vrow = os.environ.get("VROW") == "1"
         Vr = Vt.transpose(2, 3).contiguous() if vrow else None
 
         def run():
