@@ -14,7 +14,14 @@ SHAPES = [("qkv", 3072, 2048, hip.EPI_NONE), ("o", 2048, 2048, hip.EPI_RES), ("g
           ("down", 2048, 8192, hip.EPI_RES), ("lm_head", 128262, 2048, hip.EPI_NONE)]
 
 
+SHAPES_8B = [("qkv", 6144, 4096, hip.EPI_NONE), ("o", 4096, 4096, hip.EPI_RES), ("gate/up", 28672, 4096, hip.EPI_SWIGLU),
+             ("down", 4096, 14336, hip.EPI_RES), ("lm_head", 128262, 4096, hip.EPI_NONE)]
+
+
 def main():
+    global SHAPES
+    if os.environ.get("MODEL") == "8b":         # Llama-3.1-8B decode shapes (GAR-8B)
+        SHAPES = SHAPES_8B
     hip.require_device(0)
     dev = "cuda:0"
     L = 16
