@@ -773,6 +773,17 @@ def test_skinny_gemm_batched_rows_bf16(dev, M):
     o3 = torch.empty(M, Fw, dtype=dt, device=dev)
     ops.gemm(x.to(dev, dt), gu2.to(dev, dt), o3, hip.EPI_SWIGLU)
     close(o3, F.silu(xd @ gw2.double().T) * (xd @ uw2.double().T), dt)
+    # more 16-row tiles than CUs but not "wide" (Llama-3.1-8B qkv: N = 6144): two weight tiles per block for M > 32, with
+    # a ragged last block; plain, residual and the weight ring of the staged path (4 K steps in flight per wave)
+    Nm = 6144 + 16
+    wm = ww[:Nm]
+    om = torch.empty(M, Nm, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), wm.to(dev, dt), om)
+    close(om, xd @ wm.double().T, dt)
+    resm = q(rnd(M, Nm, seed=65), dt)
+    rm = resm.to(dev, dt).clone()
+    ops.gemm(x.to(dev, dt), wm.to(dev, dt), rm, hip.EPI_RES, residual=rm)
+    close(rm, resm.double() + xd @ wm.double().T, dt)
     # a row's result does not depend on the batch it rides in (up to the split-K summation order)
     o1 = torch.empty(1, N, dtype=dt, device=dev)
     ops.gemm(x[M - 1:M].to(dev, dt).contiguous(), w.to(dev, dt), o1)
