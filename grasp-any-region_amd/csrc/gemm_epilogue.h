@@ -110,11 +110,10 @@ __device__ __forceinline__ void epilogue_store8(const gar_gemm_params& p, int m,
 
 // XCD-aware tile order: the dispatcher places block b on XCD b%8; give every XCD a contiguous run of tiles (bijective
 // for any count) and walk the run in groups of GM row-panels so neighbouring blocks share A/W panels in that L2.
-// `v` = virtual block id in [0, nwg).
-__device__ __forceinline__ void tile_of(int v, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+// `v` = virtual block id in [0, nwg). GM m-tiles per group: 32 consecutive tiles of an XCD are GM x (32 / GM) tiles.
+__device__ __forceinline__ void tile_of(int v, int nwg, int tiles_m, int tiles_n, int& tm, int& tn, int GM = 8) {
     const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-    const int GM = 8;
     const int gsz = GM * tiles_n;
     const int g = wg / gsz;
     const int first_m = g * GM;
@@ -122,4 +121,18 @@ __device__ __forceinline__ void tile_of(int v, int nwg, int tiles_m, int tiles_n
     const int in = wg - g * gsz;
     tm = first_m + in % gm;
     tn = in / gm;
+}
+
+// m-tiles per group for the persistent 256 x 256 kernel: the A panels a group keeps re-reading (GM x K x 512 B) should
+// stay near the 4 MiB of an XCD's L2 — 8 panels at K = 1024, 4 at 2048, 2 at 4096, 1 from 8192 (same-box sweeps of
+// -DGAR_TILE_GM builds on the benchmark's shapes, profiles/r2_gemm_tile_group.txt: gate/up -3.4 ... -5.6 %, down
+// -2 ... -2.8 %, fc2 -0.8 % against 8 everywhere; 16 and 32 lose 4 - 30 % at K >= 4096)
+// Narrow outputs (<= 8 n-tiles) at K <= 2048 keep 8: Llama o-proj measures 0.81 ms with 8 (or 16) against 0.83 with 4.
+__device__ __forceinline__ int tile_group_m(int K, int tiles_n) {
+#ifdef GAR_TILE_GM
+    return GAR_TILE_GM;
+#else
+    if (K <= 2048 && tiles_n <= 8) return 8;
+    return max(1, min(8, 8192 / K));
+#endif
 }

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     }
 #endif
     int v = blockIdx.x, tm, tn;
-    tile_of(v, total, tiles_m, tiles_n, tm, tn);
+    const int tgm = tile_group_m(p.K, tiles_n);
+    tile_of(v, total, tiles_m, tiles_n, tm, tn, tgm);
     int m0 = tm * PBM, n0 = tn * PBM;
     stage_A(m0, 0, smem);
     stage_W(n0, 0, smem);
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         int m0n = 0, n0n = 0;
         if (has_next) {
             int tmn, tnn;
-            tile_of(vn, total, tiles_m, tiles_n, tmn, tnn);
+            tile_of(vn, total, tiles_m, tiles_n, tmn, tnn, tgm);
             m0n = tmn * PBM;
             n0n = tnn * PBM;
         }
