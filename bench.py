@@ -151,8 +151,9 @@ def cpu_baseline(cfg, W, sample, new_tokens, threads):
             "extrapolation": {"vit+projector": T / nt, "assemble+replay": 1.0, "prefill": 1.0, "decode": new_tokens / nd},
             "note": "EXTRAPOLATED from the bounded sample by the factors above. `cores` = torch intra-op threads (all "
                     "hardware threads of the box, SMT included: oversubscribed for the one-row decode GEMVs); the decode "
-                    "leg is dominated by the oracle's own bookkeeping (torch.cat KV cache growth, repeat_interleave of "
-                    "K/V for GQA), not by the reference algorithm — a reported baseline, not a tuned CPU implementation",
+                    "leg is dominated by cache bookkeeping (torch.cat KV cache growth, a materialised copy of K/V per GQA "
+                    "group) — the same bookkeeping the reference's eager CPU path does (transformers DynamicCache.update, "
+                    "repeat_kv), not arithmetic. A reported baseline, not a tuned CPU implementation",
             "seconds_per_region": total,
             "stage_seconds": {"vit+projector": t_vit, "assemble+replay": t_asm, "prefill": t_pre, "decode": t_dec}}
 
