@@ -321,18 +321,16 @@ class GARModel:
         key = ("vit", Tt)
         x = self._buf(key, "x", (Tt, N, D))
         hbuf = self._buf(key, "h", (Tt * N, D))
-        qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
         # zero-initialised once: the fused qkv GEMM writes the N real token rows only, rows N..Npad must stay finite
         Q = self._buf(key, "Q", (Tt, H, Npad, hd), zero=True)
         K = self._buf(key, "K", (Tt, H, Npad, hd), zero=True)
-        Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
         att = self._buf(key, "att", (Tt * N, Da))
+        qkv = Vt = vrow = None             # only the paths that need them allocate them (2.4 GB + 0.9 GB at 387 tiles)
         # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
         # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
         fused = self.dtype == torch.bfloat16
         # bf16: V stays row-major [Tt, H, Npad, hd] (zero-initialised like Q / K: pad rows must be finite)
         Vr = self._buf(key, "Vr", (Tt, H, Npad, hd), zero=True) if fused and self.VIT_V_ROW_MAJOR else None
-        vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
         x2 = x.view(Tt * N, D)
         gathered = False
@@ -356,12 +354,21 @@ class GARModel:
         for blk in self.vblocks:
             ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
             if fused:
-                fused = ops.gemm_qkv_rope(hbuf, blk["qkv_w"], blk["qkv_b"], vrow, Q, K, self.vit_sin, self.vit_cos, H, hd, N,
-                                          Npad, self.npt, q_scale, V=Vr)
+                if Vr is None and vrow is None:
+                    qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
+                    vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
+                    Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
+                # with V= the row-major v output is not written (att stands in for the pointer the ABI wants)
+                fused = ops.gemm_qkv_rope(hbuf, blk["qkv_w"], blk["qkv_b"], att if Vr is not None else vrow, Q, K,
+                                          self.vit_sin, self.vit_cos, H, hd, N, Npad, self.npt, q_scale, V=Vr)
             if fused and Vr is None:
                 ops.vit_v_transpose(vrow, Vt, Tt, N, H, hd, Npad)
             elif not fused:
                 Vr = None
+                if qkv is None:
+                    qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
+                if Vt is None:
+                    Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
                 ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
                 ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
             if Vr is not None:      # v left the qkv GEMM head-major like k: the attention transposes it on its LDS reads
