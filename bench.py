@@ -329,6 +329,7 @@ def main():
                                         "checks run on the device inside the timed region and their flag is read after it "
                                         "(0 here); only the host syncs are skipped",
                        "eos": "disabled (exactly new_tokens tokens per region)",
+                       "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                        "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},
             "roofline": roof}
