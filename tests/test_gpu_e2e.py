@@ -134,6 +134,32 @@ def test_batch_equals_singles_f32(tiny):
     assert torch.equal(sab, torch.cat([sa, sb]))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_planned_passes_equal_region_chunks(tiny, dt):
+    """The vision tower over chunks of image TILES and the prefill over chunks of SEQUENCES (gar_amd/planner.py; with
+    small row caps so that three samples really split: tiles cut inside a sample) give the same tokens and logits as
+    both passes over one region at a time (prefill_chunk=1) — a row's result does not depend on the pass it rides in."""
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    ss = [_sample(cfg, proc, 3 + i, dtype=dt) for i in range(3)]
+    assert len({tuple(x["input_ids"].shape) for x in ss}) == 1
+    batch = dict(input_ids=torch.cat([x["input_ids"] for x in ss]), pixel_values=torch.cat([x["pixel_values"] for x in ss]),
+                 global_mask_values=torch.cat([x["global_mask_values"] for x in ss]),
+                 bboxes=sum((x["bboxes"] for x in ss), []), aspect_ratios=torch.cat([x["aspect_ratios"] for x in ss]))
+    m1 = GARModel(cfg, W, dt, prefill_chunk=1)
+    ref = m1.generate(**batch, max_new_tokens=5, return_logits=True)
+    m2 = GARModel(cfg, W, dt)
+    tiles = batch["pixel_values"].shape[0] // 3
+    v = cfg.mllm_config.vision_config
+    m2.VIT_CHUNK_ROWS = 2 * (v.num_patches + m2.npt) * max(1, tiles // 2)       # two thirds of a sample's tiles per pass
+    m2.PREFILL_CHUNK_ROWS = 2 * batch["input_ids"].shape[1]                      # two sequences per pass
+    tc, sc = m2._plan_passes(3, tiles, batch["input_ids"].shape[1])
+    assert sum(tc) == 3 * tiles and sum(sc) == 3 and len(sc) >= 2 and any(c % tiles for c in tc)
+    out = m2.generate(**batch, max_new_tokens=5, return_logits=True)
+    assert torch.equal(out.sequences, ref.sequences)
+    assert torch.equal(out.logits, ref.logits)
+
+
 def test_bf16_against_f32_oracle_tiny(tiny):
     from gar_amd.modeling_gar import GARModel
     from oracle import gar_oracle as O
