@@ -18,7 +18,8 @@
 
 // attention_bf16.hip: DMA-staged bf16 kernel (default for bf16); false -> use the register-staged kernel below
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
-                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow, hipStream_t s);
+                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
+                          const int32_t* kv_start, hipStream_t s);
 
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
@@ -39,7 +40,8 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                         const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int Hq,
                                                         int Hkv, int q_len, int q_pad, int kv_len_arg, int kv_stride,
-                                                        const int32_t* __restrict__ kv_len_dev) {
+                                                        const int32_t* __restrict__ kv_len_dev,
+                                                        const int32_t* __restrict__ kv_start) {
     constexpr int KRS = HD * 2;                 // K tile row bytes
     constexpr int KT = 64 * KRS;                // K tile bytes   [64 kv][HD]
     constexpr int VT = HD * 128;                // Vt tile bytes  [HD][64 kv]
@@ -74,9 +76,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // kv range for this block
+    // kv range for this block (kv_start: left-padded batch, see attention_bf16.hip)
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
     int kv_end = kv_len;
-    if (CAUSAL) kv_end = min(kv_len, qb * 128 + 127 + coff + 1);
+    if (CAUSAL) kv_end = min(kv_len, max(qb * 128 + 127 + coff, kv_lo) + 1);
     const int ntiles = (kv_end + 63) / 64;
 
     // staging map: K tile = 64 rows x (KRS/16) chunks; Vt tile = HD rows x 8 chunks; 256 threads, 16 B each
@@ -117,19 +121,19 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         }
     };
 
-    if (ntiles > 0) {
-        load_tile(0);
-        write_tile(0);
+    if (ntiles > t_lo) {
+        load_tile(t_lo);
+        write_tile(t_lo & 1);
     }
     __syncthreads();
     const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2<->3 swapped
     const bool wave_active = q0 < q_len;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_lo; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) load_tile(t + 1);
         const int kv0 = t * 64;
         // wave-uniform skip: tile entirely above this wave's causal diagonal
-        const bool skip = !wave_active || (CAUSAL && kv0 > q0 + 31 + coff);
+        const bool skip = !wave_active || (CAUSAL && kv0 > max(q0 + 31 + coff, kv_lo));
         if (!skip) {
             const char* ks = smem + buf * (KT + VT);
             const char* vs = ks + KT;
@@ -148,15 +152,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
             }
             // masking (only on boundary tiles). register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
             const int qi = q0 + l31;
-            const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);
+            const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);
             if (need_mask) {
-                const int lim = CAUSAL ? min(kv_len - 1, qi + coff) : kv_len - 1;
+                const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                        s[blk][r] = kv <= lim ? s[blk][r] : -INFINITY;
+                        s[blk][r] = (kv <= lim && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                     }
             }
             float mx = -INFINITY;
@@ -237,7 +241,8 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ Vt, float* __restrict__ O, int Hq,
                                                        int Hkv, int q_len, int q_pad, int kv_len_arg, int kv_stride,
-                                                       const int32_t* __restrict__ kv_len_dev) {
+                                                       const int32_t* __restrict__ kv_len_dev,
+                                                       const int32_t* __restrict__ kv_start) {
     constexpr int KLD = HD + 1;
     constexpr int VLD = 65;
     constexpr int NDB = HD / 32;
@@ -267,11 +272,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;       // left-padded batch, see attention_bf16.hip
+    const int t_lo = kv_lo >> 6;
     int kv_end = kv_len;
-    if (CAUSAL) kv_end = min(kv_len, qb * 128 + 127 + coff + 1);
+    if (CAUSAL) kv_end = min(kv_len, max(qb * 128 + 127 + coff, kv_lo) + 1);
     const int ntiles = (kv_end + 63) / 64;
     const bool wave_active = q0 < q_len;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_lo; t < ntiles; ++t) {
         const int kv0 = t * 64;
         __syncthreads();
         for (int idx = tid; idx < 64 * (HD / 4); idx += 256) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
-        const bool skip = !wave_active || (CAUSAL && kv0 > q0 + 31 + coff);
+        const bool skip = !wave_active || (CAUSAL && kv0 > max(q0 + 31 + coff, kv_lo));
         if (skip) continue;
         f32x16 s[2];
 #pragma unroll
@@ -302,15 +309,15 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
         }
         // register r of block blk <-> kv = kv0 + 32 blk + (r&3) + 8 (r>>2) + 4 h
         const int qi = q0 + l31;
-        const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);
+        const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);
         if (need_mask) {
-            const int lim = CAUSAL ? min(kv_len - 1, qi + coff) : kv_len - 1;
+            const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    s[blk][r] = kv <= lim ? s[blk][r] : -INFINITY;
+                    s[blk][r] = (kv <= lim && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                 }
         }
         float mx = -INFINITY;
@@ -364,31 +371,31 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 template <int HD>
 static int launch_attn(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv,
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
-                       hipStream_t s) {
+                       const int32_t* kv_start, hipStream_t s) {
     dim3 grid((q_len + 127) / 128, Hq, B), block(256);
     if (dtype == GAR_BF16) {
         const int lds = 2 * (64 * HD * 2 + HD * 128);
         if (causal)
             hipLaunchKernelGGL((attn_bf16_kernel<HD, true>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev);
+                               (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
         else
             hipLaunchKernelGGL((attn_bf16_kernel<HD, false>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev);
+                               (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
     } else {
         const int lds = (64 * (HD + 1) + HD * 65) * 4;
         if (causal)
             hipLaunchKernelGGL((attn_f32_kernel<HD, true>), grid, block, lds, s, (const float*)Q, (const float*)K,
-                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev);
+                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
         else
             hipLaunchKernelGGL((attn_f32_kernel<HD, false>), grid, block, lds, s, (const float*)Q, (const float*)K,
-                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev);
+                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
     }
     return GAR_OK;
 }
 
 extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv,
                              int hd, int q_len, int q_pad, int kv_len, int kv_stride, int causal,
-                             const int32_t* kv_len_dev, gar_stream_t stream) {
+                             const int32_t* kv_len_dev, const int32_t* kv_start, gar_stream_t stream) {
     GAR_CHECK_ARG(dtype == GAR_F32 || dtype == GAR_BF16, "attention: bad dtype");
     GAR_CHECK_ARG(Q && K && Vt && O, "attention: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention: bad heads %d/%d", Hq, Hkv);
@@ -399,12 +406,12 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
                   "attention: head_dim %d not built (64, 128; 96 in bf16 only)", hd);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GAR_BF16 &&
-        gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 0, s)) {
+        gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 0, kv_start, s)) {
         GAR_CHECK_LAUNCH();
         return GAR_OK;
     }
-    if (hd == 64) launch_attn<64>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s);
-    else launch_attn<128>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, s);
+    if (hd == 64) launch_attn<64>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, kv_start, s);
+    else launch_attn<128>(dtype, Q, K, Vt, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, kv_start, s);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }
@@ -415,14 +422,14 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
 // bf16, head_dim 64 / 96 / 128; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
 extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
                                   int hd, int q_len, int q_pad, int kv_len, int kv_stride, int causal,
-                                  const int32_t* kv_len_dev, gar_stream_t stream) {
+                                  const int32_t* kv_len_dev, const int32_t* kv_start, gar_stream_t stream) {
     GAR_CHECK_ARG(Q && K && V && O, "attention_vrow: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_vrow: bad heads %d/%d", Hq, Hkv);
     GAR_CHECK_ARG(q_len > 0 && q_pad >= q_len && kv_stride % 64 == 0, "attention_vrow: bad lengths");
     GAR_CHECK_ARG(kv_len_dev || (kv_len > 0 && kv_len <= kv_stride && (!causal || kv_len >= q_len)),
                   "attention_vrow: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
     if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
-        !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1,
+        !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,
                               (hipStream_t)stream)) {
         gar_set_error("attention_vrow: built for bf16, head_dim 64 / 96 / 128 (dtype %d, head_dim %d)", dtype, hd);
         return GAR_ERR_UNSUPPORTED;

@@ -46,7 +46,8 @@ template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
-                                                              int kv_stride, const int32_t* __restrict__ kv_len_dev) {
+                                                              int kv_stride, const int32_t* __restrict__ kv_len_dev,
+                                                              const int32_t* __restrict__ kv_start) {
     // head_dim 96 (PE-G/14): K rows are 192 B in HBM; the LDS image keeps the 256-B row pitch of head_dim 128 (a
     // 4-row x 256-B DMA piece per instruction; the 64 bytes past a row's 12 real chunks are filled with a repeat of
     // chunk 11 and never read), so the fragment reads use the conflict-free head_dim-128 swizzle
@@ -153,10 +154,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     constexpr bool NEGM = (HD == 64 && (ATTN_NEGM_SET & 1)) || (HD == 128 && (ATTN_NEGM_SET & 2)) || (HD == 96 && (ATTN_NEGM_SET & 4));
     f32x16 negm = zero16_c();
 
+    // Left-padded batch (CAUSAL only; kv_start[b] = first real position of sequence b, NULL = 0): a key is visible iff
+    // kv_lo <= kv <= max(q + coff, kv_lo). Rows in front of kv_lo (padding queries, never read) see exactly key kv_lo, so every
+    // row has a visible key in the first tile it visits — the tile holding kv_lo — and the running max is finite from there.
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
     int kv_end = kv_len;
-    if (CAUSAL) kv_end = min(kv_len, qb * 128 + 127 + coff + 1);
+    if (CAUSAL) kv_end = min(kv_len, max(qb * 128 + 127 + coff, kv_lo) + 1);
     const int ntiles = (kv_end + 63) / 64;
-    if (ntiles > 0) stage(0, 0);
+    if (ntiles > t_lo) stage(t_lo, t_lo & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -185,13 +191,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     unsigned tl_n = 0u;
     const unsigned tl_begin = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_lo; t < ntiles; ++t) {
         const int buf = t & 1;
         TLA(0)
         if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
         TLA(1)
         const int kv0 = t * 64;
-        const bool skip = !wave_active || (CAUSAL && kv0 > q0 + 31 + coff);     // wave-uniform
+        const bool skip = !wave_active || (CAUSAL && kv0 > max(q0 + 31 + coff, kv_lo));     // wave-uniform
         if (!skip) {
             const char* ks = smem + buf * (KT + VT);
             const char* vs = ks + KT;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             qk();
             TLA(2)
             // register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
-            const bool need_mask = (kv0 + 64 > kv_len) || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
+            const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
             float ps = 0.f;
             bf16x8 pf[2][2];
             // p = exp2(s - m_sub) (NEGM: s already carries -m), row sum, bf16 pack
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #ifndef ATTN_LAZY_LOG2
 #define ATTN_LAZY_LOG2 16       /* 0: always the exact path (A/B) */
 #endif
-            bool exact = ATTN_LAZY_LOG2 == 0 || t == 0 || need_mask;                          // wave-uniform
+            bool exact = ATTN_LAZY_LOG2 == 0 || t == t_lo || need_mask;                       // wave-uniform
             if (!exact) {
                 exp_pack(NEGM ? 0.f : m_run);
                 exact = !__all(ps < (float)(1u << ATTN_LAZY_LOG2));
@@ -263,13 +269,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             if (exact) {
             if (need_mask) {
                 const int qi = q0 + l31;
-                const int lim = CAUSAL ? min(kv_len - 1, qi + coff) : kv_len - 1;
+                const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                        s[blk][r] = kv <= lim ? s[blk][r] : -INFINITY;
+                        s[blk][r] = (kv <= lim && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                     }
             }
             float mx = -INFINITY;
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
         __syncthreads();
         TLA(7)
 #ifdef ATTN_TIMELINE
-        if (!skip && !(CAUSAL && kv0 + 63 > q0 + coff) && kv0 + 64 <= kv_len) {     // full, unmasked tiles only
+        if (!skip && !(CAUSAL && kv0 + 63 > q0 + coff) && kv0 + 64 <= kv_len && kv0 >= kv_lo) {     // full, unmasked tiles only
             for (int i = 0; i < 7; ++i) tl_sum[i] += tl_t[i + 1] - tl_t[i];
             ++tl_n;
         }
@@ -388,14 +394,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 // returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip).
 // vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
-                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow, hipStream_t s) {
+                          int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
+                          const int32_t* kv_start, hipStream_t s) {
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
     const int kt = 64 * (hd == 64 ? 128 : 256);
     const int lds = 2 * (kt + (vrow ? kt : hd * 128));
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
-                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev)
+                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start)
     if (hd == 64) {
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }

@@ -49,7 +49,7 @@ template <int HD>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ Vt, float* __restrict__ part,
                                                                int Hq, int Hkv, int kv_stride,
-                                                               const int32_t* __restrict__ kv_len_dev,
+                                                               const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                bf16_t* __restrict__ O_direct) {
     constexpr int NKD = HD / 16, NDB = HD / 32;
     __shared__ float red[4][8][HD + 2];           // per wave: O[g][d], m, l   (g < G <= 8)
@@ -60,8 +60,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel
     const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
     const int G = Hq / Hkv;
     const int ntiles = (kv_len + 63) / 64;
-    const int per = (ntiles + nsplit - 1) / nsplit;
-    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    // left-padded batch: sequence b lives in cache rows kv_lo .. kv_len - 1; the splits divide THAT range
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
+    const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
+    const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
     bf16x8 qf[NKD];
@@ -89,13 +92,13 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel
 #pragma unroll
             for (int kd = 0; kd < NKD; ++kd)
                 s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
-        if (kv0 + 64 > kv_len) {
+        if (kv0 + 64 > kv_len || kv0 < kv_lo) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                    s[blk][r] = kv < kv_len ? s[blk][r] : -INFINITY;
+                    s[blk][r] = (kv < kv_len && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                 }
         }
         float mx = -INFINITY;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel
 __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt, float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
-                                                                 const int32_t* __restrict__ kv_len_dev,
+                                                                 const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                  bf16_t* __restrict__ O_direct) {
     constexpr int HD = 64, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | Vt 8 KiB] then red
@@ -212,8 +215,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
     const int G = Hq / Hkv;
     const int ntiles = (kv_len + 63) / 64;
-    const int per = (ntiles + nsplit - 1) / nsplit;
-    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    // left-padded batch: sequence b lives in cache rows kv_lo .. kv_len - 1; the splits divide THAT range
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
+    const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
+    const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
@@ -297,13 +303,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
 #pragma unroll
             for (int kd = 0; kd < NKD; ++kd)
                 s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
-        if (kv0 + 64 > kv_len) {
+        if (kv0 + 64 > kv_len || kv0 < kv_lo) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                    s[blk][r] = kv < kv_len ? s[blk][r] : -INFINITY;
+                    s[blk][r] = (kv < kv_len && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                 }
         }
         float mx = -INFINITY;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
 __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                     const bf16_t* __restrict__ Vt, float* __restrict__ part,
                                                                     int Hq, int Hkv, int kv_stride,
-                                                                    const int32_t* __restrict__ kv_len_dev,
+                                                                    const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                     bf16_t* __restrict__ O_direct) {
     constexpr int HD = 128, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | Vt 16 KiB] then red
@@ -404,8 +410,11 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
     const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
     const int G = Hq / Hkv;
     const int ntiles = (kv_len + 63) / 64;
-    const int per = (ntiles + nsplit - 1) / nsplit;
-    const int t0 = split * per, t1 = min(ntiles, t0 + per);
+    // left-padded batch: sequence b lives in cache rows kv_lo .. kv_len - 1; the splits divide THAT range
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
+    const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
+    const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
@@ -491,13 +500,13 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                     s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
         }
         const int kv0 = t * 64;
-        if (kv0 + 64 > kv_len) {
+        if (kv0 + 64 > kv_len || kv0 < kv_lo) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                    s[blk][r] = kv < kv_len ? s[blk][r] : -INFINITY;
+                    s[blk][r] = (kv < kv_len && kv >= kv_lo) ? s[blk][r] : -INFINITY;
                 }
         }
         float mx = -INFINITY;
@@ -625,14 +634,14 @@ extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max
 }
 
 extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq,
-                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, int max_splits, void* workspace,
-                                    gar_stream_t stream) {
+                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
+                                    int max_splits, void* workspace, gar_stream_t stream) {
     GAR_CHECK_ARG(q && Kc && Vtc && O && kv_len_dev, "attention_decode: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
     GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
     GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
     if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
-        return gar_attention(dtype, q, Kc, Vtc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, stream);
+        return gar_attention(dtype, q, Kc, Vtc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, stream);
     GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
     hipStream_t s = (hipStream_t)stream;
@@ -641,39 +650,37 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
     bf16_t* direct = max_splits == 1 ? (bf16_t*)O : nullptr;
     if (hd == 64 && (int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {      // DMA-staged kernel; else per-lane fragment loads
         constexpr int lds = 4 * 16384 + 4 * 8 * (64 + 2) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static gar_once_per_device attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_set = true;
         }
         hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     } else if (hd == 64) {
         hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     } else if ((int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {
         constexpr int lds = 4 * 32768 + 4 * 8 * (128 + 2) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static gar_once_per_device attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds128_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_set = true;
         }
         hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     } else {
         hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, direct);
+                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);

@@ -102,6 +102,33 @@ __device__ __forceinline__ float silu_fast(float x) {
 
 // ---- host side -----------------------------------------------------------------------------------------------
 void gar_set_error(const char* fmt, ...);
+// One-time setup that is per DEVICE (hipFuncSetAttribute, the CU count): a process may drive several GPUs (one GARModel
+// per device), so "done once" is keyed by the current HIP device. Devices beyond the table redo the setup every call.
+#define GAR_MAX_DEVICES 32
+static inline int gar_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = -1;
+    return d;
+}
+struct gar_once_per_device {
+    bool done[GAR_MAX_DEVICES] = {};
+    bool first() {
+        const int d = gar_current_device();
+        if (d < 0 || d >= GAR_MAX_DEVICES) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+static inline int gar_num_cus() {          // of the current device
+    static int cached[GAR_MAX_DEVICES] = {};
+    const int d = gar_current_device();
+    if (d >= 0 && d < GAR_MAX_DEVICES && cached[d] > 0) return cached[d];
+    int n = 256;
+    if (d < 0 || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    if (d >= 0 && d < GAR_MAX_DEVICES) cached[d] = n;
+    return n;
+}
 #define GAR_CHECK_ARG(cond, ...)                      \
     do {                                              \
         if (!(cond)) {                                \

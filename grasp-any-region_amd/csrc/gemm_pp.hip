@@ -46,6 +46,12 @@
 #define PP_DIAG_L2STORE false
 #endif
 
+#ifdef PP_DIRECT_EPI      /* diagnostic: 16-byte stores straight from the fragments (16 rows x 64 B per instruction), no LDS pass */
+#define PP_DIAG_DIRECT (EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_PATCH_POS)
+#else
+#define PP_DIAG_DIRECT false
+#endif
+
 #define PBM 256
 #define PBK 64
 #define PHALF (128 * 128)             // 16 KiB: 128 rows x 64 bf16
@@ -865,11 +871,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
         constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
-        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
+        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && !PP_DIAG_DIRECT && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
         } else {
             if (wm == 0) __builtin_amdgcn_s_barrier();
-            if (PERM && LDS_EPI && !PP_DIAG_NOSTORE) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+            if (PERM && LDS_EPI && !PP_DIAG_NOSTORE && !PP_DIAG_DIRECT) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
             else epilogue();
         }
 #if PP_TIMELINE == 4
@@ -902,24 +908,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 template <int EPI>
 static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hipStream_t s) {
     constexpr int LDS = 2 * PSTAGE + (EPI == GAR_EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static gar_once_per_device attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(min(pm * pn, num_cus)), dim3(512), LDS, s, p, pm, pn,
                        gar_gather_args{});                                                                      // persistent
 }
 
-static int pp_num_cus() {
-    static const int num_cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
-    return num_cus;
-}
+static int pp_num_cus() { return gar_num_cus(); }
 
 // Patch-embed + mask-embed convolutions with the patches DMA'd from the image tiles into LDS (see the GATHER notes above).
 // x[t, token_offset + patch, :] = [pixel patch | mask patch] Wg^T + pos[token_offset + patch].  Returns GAR_ERR_UNSUPPORTED
@@ -964,11 +962,10 @@ extern "C" int gar_patch_embed(int dtype, const void* pixel, const void* maskbin
     ga.patch = patch;
     ga.bytes = (unsigned)bytes;
     constexpr int LDS = 2 * PSTAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static gar_once_per_device attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>), dim3(min(pm * pn, pp_num_cus())), dim3(512), LDS,
                        (hipStream_t)stream, p, pm, pn, ga);

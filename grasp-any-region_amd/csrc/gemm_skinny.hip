@@ -301,8 +301,8 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     const bool staged = ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) &&
                         ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
     constexpr int MAXLDS = 139264;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static gar_once_per_device attr_once;
+    if (attr_once.first()) {
         if constexpr (NT <= 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
@@ -313,7 +313,6 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        attr_set = true;
     }
     // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, LDS (merge buffer, and the
     // per-wave staging regions it aliases) <= 136 KiB

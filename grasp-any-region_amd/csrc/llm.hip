@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
                                                            const float* __restrict__ sn, T* __restrict__ Q,
                                                            T* __restrict__ Kc, T* __restrict__ Vtc, int S, int Spad,
                                                            int Hq, int Hkv, int Smax, int pos0,
-                                                           const int32_t* __restrict__ pos_dev, float q_scale) {
+                                                           const int32_t* __restrict__ pos_dev,
+                                                           const int32_t* __restrict__ left_pad, float q_scale) {
     constexpr int HALF = HD / 2;
     constexpr int LPT = HALF / 8;               // lanes per token (4 for hd 64, 8 for hd 128)
     constexpr int TPP = 256 / LPT;              // tokens per pass (64 / 32)
@@ -23,6 +24,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
     const int tid = threadIdx.x;
     const int i8 = (tid % LPT) * 8;
     const int p0 = pos_dev ? pos_dev[0] : pos0;
+    // left-padded batch (HF generation): sequence b starts at row left_pad[b]; the CACHE row of a token stays its row in the
+    // padded sequence, only its RoPE position is counted from the first real token (rows before it: position 0, never read)
+    const int lp = left_pad ? left_pad[b] : 0;
     const int W = (Hq + 2 * Hkv) * HD;
     // rotary heads (q, k): a thread keeps its token and its 8-wide slice for every head, so cos / sin are loaded once per
     // pass and the rows of RU heads are in flight together (a CU holds 16 waves: the latency cover has to come from here)
@@ -32,8 +36,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
         const int s = ch * 64 + nl;
         float c[8], sv[8];
         if (s < S) {
-            ld8(cs + (int64_t)(p0 + s) * HALF + i8, c);
-            ld8(sn + (int64_t)(p0 + s) * HALF + i8, sv);
+            const int rp = max(p0 + s - lp, 0);
+            ld8(cs + (int64_t)rp * HALF + i8, c);
+            ld8(sn + (int64_t)rp * HALF + i8, sv);
         }
         for (int head0 = 0; head0 < Hq + Hkv; head0 += RU) {
             float x1[RU][8], x2[RU][8];
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
                                                                   const float* __restrict__ sn, T* __restrict__ Q,
                                                                   T* __restrict__ Kc, T* __restrict__ Vtc, int B, int Spad,
                                                                   int Hq, int Hkv, int Smax, int pos0,
-                                                                  const int32_t* __restrict__ pos_dev, float q_scale) {
+                                                                  const int32_t* __restrict__ pos_dev,
+                                                                  const int32_t* __restrict__ left_pad, float q_scale) {
     constexpr int HALF = HD / 2, LPH = HALF / 8;
     const int nh = Hq + 2 * Hkv;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,8 +147,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
     ld8(row + i8, x1);
     ld8(row + HALF + i8, x2);
     if (head < Hq + Hkv) {
-        const float* cp = cs + (int64_t)p0 * HALF + i8;
-        const float* sp = sn + (int64_t)p0 * HALF + i8;
+        const int rp = max(p0 - (left_pad ? left_pad[b] : 0), 0);          // RoPE position; the cache row stays p0
+        const float* cp = cs + (int64_t)rp * HALF + i8;
+        const float* sp = sn + (int64_t)rp * HALF + i8;
         const float sc = head < Hq ? q_scale : 1.0f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
 
 extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, const float* sn, void* Q, void* Kc,
                                 void* Vtc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
-                                const int32_t* pos_dev, float q_scale, gar_stream_t stream) {
+                                const int32_t* pos_dev, const int32_t* left_pad, float q_scale, gar_stream_t stream) {
     GAR_CHECK_ARG(qkv && cs && sn && Q && Kc && Vtc, "llm_qkv_post: null pointer");
     GAR_CHECK_ARG(B > 0 && S > 0 && Spad >= S && Smax % 64 == 0, "llm_qkv_post: bad shape");
     GAR_CHECK_ARG(pos_dev || pos0 + S <= Smax, "llm_qkv_post: cache overflow %d+%d > %d", pos0, S, Smax);
@@ -179,7 +186,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
         dim3 g1((total + 255) / 256), b1(256);
 #define LAUNCH_LQD(TT, HD_)                                                                                         \
     hipLaunchKernelGGL((llm_qkv_post_decode_kernel<TT, HD_>), g1, b1, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc, \
-                       (TT*)Vtc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, q_scale)
+                       (TT*)Vtc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
         if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQD(bf16_t, 64); else LAUNCH_LQD(bf16_t, 128); }
         else { if (hd == 64) LAUNCH_LQD(float, 64); else LAUNCH_LQD(float, 128); }
 #undef LAUNCH_LQD
@@ -189,7 +196,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
     dim3 grid(B * ((Spad + 63) / 64)), block(256);
 #define LAUNCH_LQP(TT, HD_)                                                                                       \
     hipLaunchKernelGGL((llm_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc,  \
-                       (TT*)Vtc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, q_scale)
+                       (TT*)Vtc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
     if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQP(bf16_t, 64); else LAUNCH_LQP(bf16_t, 128); }
     else { if (hd == 64) LAUNCH_LQP(float, 64); else LAUNCH_LQP(float, 128); }
 #undef LAUNCH_LQP

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
 GAR_F32, GAR_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GarError(RuntimeError):
@@ -49,11 +49,11 @@ SIGNATURES = {
     "gar_splitk_residual_rmsnorm": ([_i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "gar_vit_v_transpose": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
-    "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp], _i),
-    "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
-    "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp], _i),
+    "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
-    "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
+    "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gar_pool2x2":([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "gar_pool_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp], _i),

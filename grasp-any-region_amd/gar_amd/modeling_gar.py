@@ -269,6 +269,7 @@ class GARModel:
     # the KV-cache states are kept in an LRU of MAX_LLM_STATES entries (their graphs go with them).
     _CAPACITY_FAMILIES = ("vit", "emb", "prefill")
     MAX_LLM_STATES = 2
+    SPLITK_MAX_ROWS = 64      # csrc/gemm.hip: split_k > 1 and gar_splitk_residual_rmsnorm are built for M <= 64 rows
     DOWN_SPLIT_K = 2          # K slices of the decode `down` GEMM at more than FUSE_NORM_MAX_BATCH rows (1 = off; 2 and 4
                               # measure the same 21.6-21.9 us per layer against 28.6 unsplit, tools/bench_skinny.py)
 
@@ -504,12 +505,20 @@ class GARModel:
             self._ws.pop(old, None)
             for gk in [g for g in self._graphs if g[0] == old]:
                 del self._graphs[gk]
+            # the per-batch decode / head workspaces (logits [B, vocab], attention partials, split-K slices) go with the
+            # last live state of that batch size: a service that sees many distinct B does not accumulate them
+            if not any(k[1] == old[1] for k in self._llm_lru):
+                self._ws.pop(("decode", old[1]), None)
+                self._ws.pop(("head", old[1]), None)
         L, Hkv, hd = t.num_hidden_layers, t.num_key_value_heads, t.head_dim
         st = dict(
             Kc=self._buf(key, "Kc", (L, B, Hkv, Smax, hd), zero=True),
             Vtc=self._buf(key, "Vtc", (L, B, Hkv, hd, Smax), zero=True),
             counters=self._buf(key, "counters", (4,), torch.int32, zero=True),   # [pos, kv_len, step, -]
             cur=self._buf(key, "cur", (B,), torch.int64, zero=True),
+            # first real row of every sequence (left-padded batch; zeros otherwise): read by the qkv-post and attention
+            # kernels of the prefill and of the captured decode step, so one graph serves padded and unpadded requests
+            left_pad=self._buf(key, "left_pad", (B,), torch.int32, zero=True),
         )
         return key, st
 
@@ -528,12 +537,13 @@ class GARModel:
         ff = self._buf(key, "ff", (B * S, F))
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
+        lp = st["left_pad"][b0:b0 + B]
         for li, ly in enumerate(self.layers):
             Kc, Vtc = st["Kc"][li][b0:b0 + B], st["Vtc"][li][b0:b0 + B]       # this chunk's rows of the shared cache
             ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
             ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale)
-            ops.attention(Q, Kc, Vtc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
+            ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale, left_pad=lp)
+            ops.attention(Q, Kc, Vtc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp)
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
             ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
             ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
@@ -582,8 +592,10 @@ class GARModel:
         fuse = B <= self.FUSE_NORM_MAX_BATCH     # every block redoes x*g in the prologue: only pays for <= 16 rows
         # `down` (K = intermediate size, only hidden/16 weight tiles) streams from DOWN_SPLIT_K x the workgroups as K slices
         # whose fp32 products are reduced — with the residual add and the next RMSNorm — by the launch that follows anyway
-        split = self.DOWN_SPLIT_K if (not fuse and self.dtype == torch.bfloat16 and F % (64 * self.DOWN_SPLIT_K) == 0
-                                      and C_l <= 4096) else 1
+        # (gar_gemm's split_k and gar_splitk_residual_rmsnorm take at most SPLITK_MAX_ROWS rows; larger batches keep the tile
+        # GEMM with EPI_RES + a separate RMSNorm)
+        split = self.DOWN_SPLIT_K if (not fuse and B <= self.SPLITK_MAX_ROWS and self.dtype == torch.bfloat16
+                                      and F % (64 * self.DOWN_SPLIT_K) == 0 and C_l <= 4096) else 1
         partial = self._buf(key, "down_partial", (split, B, C_l), torch.float32) if split > 1 else None
         normed = None
         for li, ly in enumerate(self.layers):
@@ -593,8 +605,10 @@ class GARModel:
                 if split == 1 or li == 0:
                     ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale)
-            ops.attention_decode(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws)
+            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
+                             left_pad=st["left_pad"])
+            ops.attention_decode(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
+                                 kv_start=st["left_pad"])
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
             if fuse:
                 ops.gemm(h, ly["gu"], ff, hip.EPI_SWIGLU, norm_w=ly["ln2"], norm_eps=t.rms_norm_eps)
@@ -669,8 +683,24 @@ class GARModel:
         max_new_tokens = int(max_new_tokens or 64)
         cfg = self.config
         B, S = input_ids.shape
-        if validate and attention_mask is not None and not bool((attention_mask != 0).all()):
-            raise hip.GarError("padded attention_mask is not supported (the reference's callers pass all ones)")
+        # attention_mask is forwarded to the Llama generate by the reference (modeling_gar.py:418-426). A LEFT-padded batch
+        # (HF's convention for generation: prompts of different lengths right-aligned, zeros in front) is supported: a
+        # sequence keeps its rows in the padded layout, its RoPE positions count from its first real token and the padding
+        # keys stay hidden (HF: position_ids = cumsum(mask) - 1, causal mask AND attention_mask).
+        left_pad = None
+        if attention_mask is not None:
+            am = (attention_mask != 0)
+            if tuple(am.shape) != (B, S):
+                raise ValueError(f"attention_mask {tuple(am.shape)} does not match input_ids {(B, S)}")
+            if validate:
+                amc = am.cpu()
+                if not bool(amc.all()):
+                    if not bool((amc[:, 1:] >= amc[:, :-1]).all()) or not bool(amc[:, -1].all()):
+                        raise hip.GarError("attention_mask must be LEFT-padded (zeros only in front of every prompt): a "
+                                           "right-padded row would be continued after its padding")
+                    left_pad = (S - amc.sum(1)).to(torch.int32).to(self.device)
+            else:                      # no host sync: the mask is trusted to be left-padded, its zero count is the pad
+                left_pad = (S - am.to(self.device).sum(1)).to(torch.int32)
         # KV capacity in buckets of 256 positions: evaluation loops with a different prompt length per item reuse one
         # cache, one token buffer ([B, Smax], sliced) and one captured decode graph per bucket
         if forced_tokens is not None:
@@ -679,6 +709,10 @@ class GARModel:
         skey, st = self._llm_state(B, Smax)
         out_tokens = self._buf(skey, "out_tokens", (B, Smax), torch.int64, zero=True)[:, :max_new_tokens]
         st["counters"].zero_()
+        if left_pad is None:
+            st["left_pad"].zero_()
+        else:
+            st["left_pad"].copy_(left_pad)
         V = cfg.mllm_config.text_config.vocab_size
         tiles = 0
         if pixel_values is not None:

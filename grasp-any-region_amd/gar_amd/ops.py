@@ -243,25 +243,30 @@ def vit_v_transpose(v, Vt, T, N, H, hd, Npad):
           "gar_vit_v_transpose")
 
 
-def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale):
+def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None):
+    """``left_pad`` int32 [B] (device) or None: first real row of each sequence of a left-padded batch."""
     check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vtc), B, S,
-                                 Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), q_scale, stream()), "gar_llm_qkv_post")
+                                 Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), ptr(left_pad), q_scale, stream()),
+          "gar_llm_qkv_post")
 
 
 def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None,
-              v_row_major: bool = False):
-    """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout; bf16, head_dim 64) instead of its transpose."""
+              v_row_major: bool = False, kv_start=None):
+    """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout; bf16, head_dim 64) instead of its transpose.
+    ``kv_start`` int32 [B] (device) or None: first visible kv row per sequence (left-padded batch)."""
     if v_row_major:
         check(lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
-                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention_vrow")
+                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()),
+              "gar_attention_vrow")
         return
     check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
-                              kv_len, kv_stride, int(causal), ptr(kv_len_dev), stream()), "gar_attention")
+                              kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention")
 
 
-def attention_decode(q, Kc, Vtc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace):
+def attention_decode(q, Kc, Vtc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None):
     check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vtc), ptr(O), B, Hq, Hkv, hd, Smax,
-                                     ptr(kv_len_dev), max_splits, ptr(workspace), stream()), "gar_attention_decode")
+                                     ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
+          "gar_attention_decode")
 
 
 def attention_decode_workspace(B, Hq, hd, max_splits) -> int:

@@ -148,7 +148,17 @@ def synthetic_weights(cfg, seed: int = 0, names: Iterable[str] = None) -> Dict[s
     if names is None:
         names = shapes.keys()
     sharp = SHALLOW_ATTN_SHARPNESS if cfg.mllm_config.text_config.num_hidden_layers <= 4 else 1.0
-    return {n: synthetic_tensor(n, shapes[n], seed, sharp) for n in names}
+    names = list(names)
+    total = sum(math.prod(shapes[n]) for n in names)
+    if total < (1 << 28):
+        return {n: synthetic_tensor(n, shapes[n], seed, sharp) for n in names}
+    # every tensor has its own seeded generator, so drawing them on a few threads gives the same values (normal_ releases
+    # the GIL): GAR-8B's 8e9 parameters take minutes on one core
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // 2))) as ex:
+        vals = list(ex.map(lambda n: synthetic_tensor(n, shapes[n], seed, sharp), names))
+    return dict(zip(names, vals))
 
 
 def save_weights(weights: Dict[str, torch.Tensor], path: str) -> None:
@@ -188,14 +198,15 @@ def normalize_checkpoint(cfg, weights: Dict[str, torch.Tensor]) -> Dict[str, tor
       captions: a post-transformer ``norm.{weight,bias}`` / ``use_post_transformer_norm`` (the reference applies
       ``self.norm``, modeling_perception_lm.py:216; PE-lang checkpoints have Identity there), a non-zero
       ``patch_embed.proj.bias``, ``attn.{q,k}_norm``, a ``ref_feat_shape`` different from the feature grid (RoPE rescale);
-    * an untied ``mllm.lm_head.weight`` that differs from ``embed_tokens`` wins over a config that says (or defaults
-      to) ``tie_word_embeddings``.
+    * an ``mllm.lm_head.weight`` that differs from ``embed_tokens`` under a config that says (or defaults to)
+      ``tie_word_embeddings`` raises (HF's ``tie_weights()`` would silently discard it); an identical one is fine.
     Modifies ``cfg`` in place, returns a new dict; nothing is copied unless it has to be concatenated."""
     import re
     v = cfg.mllm_config.vision_config
     W = dict(weights)
     unsupported = [k for k in W if k.startswith(VT) and (
-        k[len(VT):] in ("norm.weight", "norm.bias", "fc_norm.weight", "fc_norm.bias") or
+        k[len(VT):] in ("norm.weight", "norm.bias") or       # fc_norm.* belongs to timm's forward_head, which
+        # the PerceptionLM tower never calls (forward_features only): ignored like the other head tensors
         ".attn.q_norm." in k or ".attn.k_norm." in k or ".attn.norm." in k)]
     pb = W.get(VT + "patch_embed.proj.bias")
     if pb is not None and bool((pb != 0).any()):
@@ -214,7 +225,11 @@ def normalize_checkpoint(cfg, weights: Dict[str, torch.Tensor]) -> Dict[str, tor
         t = cfg.mllm_config.text_config
         same = head.shape == emb.shape and (head.data_ptr() == emb.data_ptr() or bool(torch.equal(head, emb)))
         if t.tie_word_embeddings and not same:
-            t.tie_word_embeddings = False          # the checkpoint's own head, not a silent fallback to the embedding
+            # HF's tie_weights() would overwrite this head with the embedding; a checkpoint whose head differs under a
+            # config that ties is inconsistent — refuse instead of picking one of the two behind the caller's back
+            raise ValueError("checkpoint holds an mllm.lm_head.weight that differs from embed_tokens but the config says "
+                             "tie_word_embeddings=True (HF would discard the head); set text_config.tie_word_embeddings="
+                             "False to use the checkpoint's head")
     blocks = set()
     pat = re.compile(re.escape(VT) + r"blocks\.(\d+)\.")
     for k in W:

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 6
+#define GAR_ABI_VERSION 7
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -153,19 +153,25 @@ int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T, int N, int H,
 /* HF Llama pre-attention step on fused qkv [B*S, (Hq+2Hkv)*hd]: half-split RoPE (cos/sin [max_pos, hd/2] f32,
  * row = absolute position pos0+s), q scale folded, Q [B,Hq,Spad,hd]; K and V appended to the cache at
  * positions pos0..pos0+S-1:  Kc [B,Hkv,Smax,hd], Vtc [B,Hkv,hd,Smax].
- * If `pos_dev` != NULL the start position is read from device memory (pos_dev[0]) instead of pos0 (graph replay). */
+ * If `pos_dev` != NULL the start position is read from device memory (pos_dev[0]) instead of pos0 (graph replay).
+ * `left_pad` (device int32 [B] or NULL): a LEFT-PADDED batch as HF generation builds it from `attention_mask`
+ * (modeling_gar.py:418-426 forwards it): sequence b's first real token sits at row left_pad[b]; a token keeps its row in
+ * the cache and rotates by position (row - left_pad[b]) (HF: position_ids = cumsum(attention_mask) - 1). */
 int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* sin, void* Q, void* Kc, void* Vtc,
                      int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0, const int32_t* pos_dev,
-                     float q_scale, gar_stream_t stream);
+                     const int32_t* left_pad, float q_scale, gar_stream_t stream);
 
 /* Flash-style attention (replaces F.scaled_dot_product_attention in timm AttentionRope and flash-attn-2 /
  * eager attention in HF Llama, modeling_gar.py:40-43). Q [B,Hq,q_pad,hd] (pre-scaled by scale*log2e),
  * K [B,Hkv,kv_stride,hd], Vt [B,Hkv,hd,kv_stride] (entries beyond kv_len must be finite); O [B*q_len, Hq*hd]
  * token-major. causal: query i attends kv j <= i + (kv_len - q_len).
- * If `kv_len_dev` != NULL the kv length is read from device memory (decode step inside a replayed graph). */
+ * If `kv_len_dev` != NULL the kv length is read from device memory (decode step inside a replayed graph).
+ * `kv_start` (device int32 [B] or NULL = 0): first visible kv row of sequence b — the padding keys of a left-padded
+ * batch stay hidden (HF combines the causal mask with `attention_mask`): query i sees kv_start[b] <= j <= max(i + kv_len -
+ * q_len, kv_start[b]); rows in front of kv_start[b] are padding queries (finite output nobody reads). */
 int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd,
                   int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
-                  gar_stream_t stream);
+                  const int32_t* kv_start, gar_stream_t stream);
 /* The same with V row-major, [B,Hkv,kv_stride,hd] like K (what GAR_EPI_QKV_ROPE writes to gar_gemm_params.qkv_v): the PV
  * operand is formed by gfx950's transposing LDS read (ds_read_b64_tr_b16), so timm AttentionRope's v needs no transpose
  * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64 /
@@ -173,16 +179,18 @@ int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void*
  * GAR_ERR_UNSUPPORTED (nothing launched) otherwise. */
 int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd,
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
-                       gar_stream_t stream);
+                       const int32_t* kv_start, gar_stream_t stream);
 
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
  * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / Vt.
  * q [B,Hq,hd] pre-scaled; kv length = kv_len_dev[0] (device memory, so one captured hipGraph replays for every
- * token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes. GAR_F32 routes to gar_attention. */
+ * token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes. GAR_F32 routes to gar_attention.
+ * `kv_start` (device int32 [B] or NULL): sequence b's keys are cache rows kv_start[b] .. kv_len - 1 (left-padded batch);
+ * the kv splits divide that range. */
 int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits);
 int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq, int Hkv,
-                         int hd, int Smax, const int32_t* kv_len_dev, int max_splits, void* workspace,
-                         gar_stream_t stream);
+                         int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits,
+                         void* workspace, gar_stream_t stream);
 
 /* PerceptionLMAdaptiveAvgPooling (modeling_perception_lm.py:47-60): per tile [g*g, C] -> [(g/2)^2, C], exact 2x2
  * mean. Input tile t starts at row t*in_tile_tokens + in_token_offset of x (lets the projector run over the

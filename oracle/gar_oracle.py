@@ -396,14 +396,32 @@ class KVCache:
 
 
 def llama_forward(inputs_embeds: torch.Tensor, W: Dict[str, torch.Tensor], tcfg, cache: KVCache,
-                  attn_impl: str = "eager", return_layers: bool = False):
+                  attn_impl: str = "eager", return_layers: bool = False, attention_mask: torch.Tensor = None):
     """LlamaModel.forward over ``inputs_embeds`` [B,S,C] appended after ``cache.length`` positions.
-    Returns final-normed hidden states [B,S,C]."""
+    Returns final-normed hidden states [B,S,C].
+
+    ``attention_mask`` [B, cache.length + S] (1 = real token, 0 = padding; HF generation left-pads): what
+    GenerationMixin does with it for a Llama (transformers generation/utils.py prepare_inputs_for_generation +
+    masking_utils): position_ids = cumsum(mask) - 1 with padding positions set to 1, and a key is visible to a query iff
+    it is causal AND not padding. Rows at padding positions are computed like any other (their values are never read by a
+    real row)."""
     B, S, C = inputs_embeds.shape
     Hq, Hkv, hd = tcfg.num_attention_heads, tcfg.num_key_value_heads, tcfg.head_dim
     p0 = cache.length
-    pos = torch.arange(p0, p0 + S)
-    cos, sin = llama_rope_tables(tcfg, pos)
+    padded = attention_mask is not None and not bool((attention_mask != 0).all())
+    if padded:
+        am = (attention_mask != 0)
+        assert am.shape == (B, p0 + S)
+        pid = am.long().cumsum(-1) - 1
+        pid = pid.masked_fill(~am, 1)[:, p0:]                                    # [B, S]
+        inv = llama_inv_freq(tcfg)
+        freqs = pid.to(torch.float32)[:, :, None] * inv[None, None, :]
+        embp = torch.cat((freqs, freqs), dim=-1)
+        cos, sin = embp.cos()[:, None], embp.sin()[:, None]                      # [B, 1, S, hd]
+        attn_impl = "eager"
+    else:
+        pos = torch.arange(p0, p0 + S)
+        cos, sin = llama_rope_tables(tcfg, pos)
     h = inputs_embeds
     layers = []
     for i in range(tcfg.num_hidden_layers):
@@ -428,6 +446,8 @@ def llama_forward(inputs_embeds: torch.Tensor, W: Dict[str, torch.Tensor], tcfg,
         else:
             s = (q @ kk.transpose(2, 3)) * (hd ** -0.5)
             m = torch.ones(S, L, dtype=torch.bool).tril(diagonal=L - S)
+            if padded:
+                m = m[None, None] & am[:, None, None, :]                         # [B, 1, S, L]: causal and not padding
             s = s.masked_fill(~m, torch.finfo(s.dtype).min)
             a = torch.softmax(s, dim=-1, dtype=torch.float32) @ vv
         a = a.transpose(1, 2).reshape(B, S, Hq * hd)
@@ -447,17 +467,19 @@ def lm_head_weight(W, tcfg):
 
 
 def greedy_generate(inputs_embeds: torch.Tensor, W, tcfg, max_new_tokens: int, eos_token_id=None,
-                    attn_impl: str = "eager", return_logits: bool = False):
+                    attn_impl: str = "eager", return_logits: bool = False, attention_mask: torch.Tensor = None):
     """GenerationMixin greedy search started from ``inputs_embeds`` (modeling_gar.py:418-426): returns only
-    the new tokens [B, n_new]. Stops when every sequence has produced EOS (finished rows emit EOS as pad)."""
+    the new tokens [B, n_new]. Stops when every sequence has produced EOS (finished rows emit EOS as pad).
+    ``attention_mask`` [B, S] of a left-padded batch is extended by a column of ones per generated token."""
     B = inputs_embeds.shape[0]
+    am = None if attention_mask is None else (attention_mask != 0).long()
     E = W[LM + "embed_tokens.weight"]
     head = lm_head_weight(W, tcfg)
     cache = KVCache(tcfg.num_hidden_layers)
     eos = set()
     if eos_token_id is not None:
         eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else {int(eos_token_id)}
-    h = llama_forward(inputs_embeds, W, tcfg, cache, attn_impl)
+    h = llama_forward(inputs_embeds, W, tcfg, cache, attn_impl, attention_mask=am)
     out_tokens, all_logits = [], []
     finished = torch.zeros(B, dtype=torch.bool)
     pad = next(iter(eos)) if eos else 0
@@ -473,7 +495,9 @@ def greedy_generate(inputs_embeds: torch.Tensor, W, tcfg, max_new_tokens: int, e
             if bool(finished.all()):
                 break
         if step + 1 < max_new_tokens:
-            h = llama_forward(F.embedding(nxt, E).unsqueeze(1), W, tcfg, cache, attn_impl)
+            if am is not None:
+                am = torch.cat([am, torch.ones(B, 1, dtype=am.dtype)], dim=1)
+            h = llama_forward(F.embedding(nxt, E).unsqueeze(1), W, tcfg, cache, attn_impl, attention_mask=am)
     seq = torch.stack(out_tokens, dim=1)
     return (seq, torch.stack(all_logits, dim=1)) if return_logits else seq
 
@@ -502,11 +526,10 @@ def build_inputs_embeds(W, cfg, pixel_values, global_mask_values, aspect_ratios,
 def gar_generate(W, cfg, pixel_values, global_mask_values, aspect_ratios, bboxes, input_ids,
                  attention_mask=None, max_new_tokens: int = 64, eos_token_id=None,
                  attn_impl: str = "eager", return_logits: bool = False, video_frame_tokens=None):
-    """Restates GARModel.generate for fp32 CPU tensors. ``attention_mask`` must be all ones (the only case the
-    reference's callers produce, eval_dataset.py:143). ``video_frame_tokens`` selects the video replay (A13)."""
-    if attention_mask is not None:
-        assert bool((attention_mask != 0).all()), "oracle handles the unpadded case only"
+    """Restates GARModel.generate for fp32 CPU tensors. ``attention_mask`` is forwarded to the Llama generate like the
+    reference does (modeling_gar.py:418-426; its own callers pass all ones, eval_dataset.py:143; a left-padded batch
+    follows HF's position / masking rules, see llama_forward). ``video_frame_tokens`` selects the video replay (A13)."""
     embeds = build_inputs_embeds(W, cfg, pixel_values, global_mask_values, aspect_ratios, bboxes, input_ids,
                                  attn_impl, video_frame_tokens=video_frame_tokens)
     return greedy_generate(embeds, W, cfg.mllm_config.text_config, max_new_tokens, eos_token_id, attn_impl,
-                           return_logits)
+                           return_logits, attention_mask=attention_mask)

@@ -70,11 +70,11 @@ def test_f32_greedy_parity_tiny(tiny, multi):
     assert m.generate(**s, max_new_tokens=12).sequences.cpu().tolist() == ref_seq.tolist()
 
 
-def _video_sample(cfg, proc, n_frames=3, dtype=torch.float32, base=50):
+def _video_sample(cfg, proc, n_frames=3, dtype=torch.float32, base=50, w=180, h=150):
     from gar_amd.eval_dataset import VideoRegionCaptionDataset
     from gar_amd.synthetic import synthetic_image, synthetic_mask
-    frames = [synthetic_image(base + f, 180, 150) for f in range(n_frames)]
-    masks = [synthetic_mask(base + 10 + f, 180, 150) for f in range(n_frames)]
+    frames = [synthetic_image(base + f, w, h) for f in range(n_frames)]
+    masks = [synthetic_mask(base + 10 + f, w, h) for f in range(n_frames)]
     return VideoRegionCaptionDataset(frames, masks, proc, data_dtype=dtype, device="cpu")[0]
 
 
@@ -418,6 +418,55 @@ def test_f32_video_replay_gar8b_structure_tiny():
     _check_f32(m.generate(**s, max_new_tokens=8, return_logits=True), ref_seq, ref_logits)
 
 
+def test_video_replay_gar8b_dims_one_layer():
+    """BASELINE.json configs[4] at its real dimensions (one layer each): an 8-frame 1024^2 clip with a per-frame mask
+    through the GAR-8B video replay — C = 4096, eight 256-row replays per clip (the 8-job instantiation of
+    roi_replay_inplace at C = 4096), S ~ 4.3k, PE-G/14 head_dim 96 without cls token, Llama head_dim 128, untied head.
+    (1) f32 HIP vs the oracle: tokens and per-step logits; (2) bf16 HIP vs the oracle on the bf16-rounded weights;
+    (3) a batch of two clips (16 RoI jobs in one launch) equals the single runs."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    from oracle import gar_oracle as O
+    cfg = GARConfig.gar_8b(**{"vision.depth": 1, "text.num_hidden_layers": 1})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=8)
+    s = _video_sample(cfg, proc, 8, base=90, w=1024, h=1024)
+    assert s["pixel_values"].shape[0] == 8 and len(s["bboxes"][0]) == 8 and s["input_ids"].shape[1] > 4200
+    n = 4
+    ref_seq, ref_logits = O.gar_generate(W, cfg, s["pixel_values"], s["global_mask_values"], None, s["bboxes"],
+                                         s["input_ids"], None, max_new_tokens=n, return_logits=True,
+                                         video_frame_tokens=s["video_frame_tokens"], attn_impl="sdpa")
+    m = GARModel(cfg, W, torch.float32)
+    _check_f32(m.generate(**s, max_new_tokens=n, return_logits=True), ref_seq, ref_logits, "f32 graph")
+    # the replayed rows themselves, against the oracle's inputs_embeds
+    proj = m.get_image_features(s["pixel_values"], s["global_mask_values"], pooled=False)
+    emb = m.build_inputs_embeds(s["input_ids"], None, s["bboxes"], None, 8, True, s["video_frame_tokens"], proj=proj).cpu().clone()
+    ref_emb = O.build_inputs_embeds(W, cfg, s["pixel_values"], s["global_mask_values"], None, s["bboxes"], s["input_ids"],
+                                    video_frame_tokens=s["video_frame_tokens"])
+    assert _rel_l2(emb, ref_emb) < 1e-5
+    s2 = _video_sample(cfg, proc, 8, base=130, w=1024, h=1024)
+    two = dict(input_ids=torch.cat([s["input_ids"], s2["input_ids"]]), pixel_values=torch.cat([s["pixel_values"], s2["pixel_values"]]),
+               global_mask_values=torch.cat([s["global_mask_values"], s2["global_mask_values"]]),
+               bboxes=s["bboxes"] + s2["bboxes"], feature_replay_video=True, video_frame_tokens=s["video_frame_tokens"])
+    o2 = m.generate(**s2, max_new_tokens=n).sequences
+    o12 = m.generate(**two, max_new_tokens=n).sequences
+    assert o12[0].cpu().tolist() == ref_seq[0].tolist() and torch.equal(o12[1], o2[0])
+    del m
+    torch.cuda.empty_cache()
+    Wq = {k: v.to(torch.bfloat16).float() for k, v in W.items()}
+    refq_seq, refq_logits = O.gar_generate(Wq, cfg, s["pixel_values"].to(torch.bfloat16).float(),
+                                           s["global_mask_values"].to(torch.bfloat16).float(), None, s["bboxes"],
+                                           s["input_ids"], None, max_new_tokens=1, return_logits=True,
+                                           video_frame_tokens=s["video_frame_tokens"], attn_impl="sdpa")
+    sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in s.items()}
+    mb = GARModel(cfg, W, torch.bfloat16)
+    ob = mb.generate(**sb, max_new_tokens=n, return_logits=True)
+    assert _rel_l2(ob.logits.cpu()[:, 0], refq_logits[:, 0]) < BF16_LOGIT_TOL
+    assert torch.equal(mb.generate(**sb, max_new_tokens=n, use_graph=False).sequences, ob.sequences)
+
+
 def test_replica_from_shapes_after_weight_copy(tiny):
     """the non-source ranks of the data-parallel runner build the model from shapes only and receive the PREPARED weight
     tensors by RCCL broadcast (bench.py): emulate the broadcast with copies and require identical captions — also for
@@ -571,7 +620,7 @@ def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert max(rel) < FULL_DEPTH_BF16_REL_L2, max(rel)
     for j in (~agree).nonzero().flatten().tolist():
         assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
-    assert rate >= 0.75, rate
+    assert rate >= 0.85, rate          # measured 0.906; a regression in a bf16 kernel must not hide below it
     # free-running bf16 through the graph == the same model run eagerly (bit-identical kernels)
     free_g = m16.generate(**sb, max_new_tokens=16)
     free_e = m16.generate(**sb, max_new_tokens=16, use_graph=False)
@@ -607,3 +656,86 @@ def test_config0_demo_asset_f32_parity(golden_dir, max_num_tiles, canvas):
     sd = SingleRegionCaptionDataset(img, mask, proc, data_dtype=torch.float32, device="cuda:0")[0]
     assert torch.equal(sd["pixel_values"].cpu(), s["pixel_values"])
     assert m.generate(**sd, max_new_tokens=8).sequences.cpu().tolist() == ref_seq.tolist()
+
+
+FULL_DEPTH_8B_F32_TOL = 2e-4
+FULL_DEPTH_8B_BF16_REL_L2 = 8e-2     # 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: 6e-2); measured value printed
+
+
+def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
+    """Full GAR-8B (BASELINE.json configs[3]: 47 PE-G/14 layers with head_dim 96 and no cls token + 32 Llama-3.1-8B layers
+    with head_dim 128 and an untied head; max_num_tiles=8 -> 5 tiles, S ~ 1.6k):
+    (1) f32 HIP vs the CPU oracle — the first 2 greedy tokens (prefill + one decode step) and their logits;
+    (2) bf16 HIP vs f32 HIP teacher-forced over 32 tokens: per-step relative L2 of the logits, top-1 agreement, every
+        disagreement at an f32 margin inside the measured bf16 logit error."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_8b()
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=8)
+    s = _sample(cfg, proc, 0, 1024, 1024)
+    assert s["pixel_values"].shape[0] == 5
+    ref_seq, ref_logits = _oracle(W, cfg, s, 2, attn_impl="sdpa")
+    NT = 32
+    m32 = GARModel(cfg, W, torch.float32)
+    o32 = m32.generate(**s, max_new_tokens=NT, return_logits=True)
+    err = float((o32.logits[:, :2].cpu() - ref_logits).abs().max()) / float(ref_logits.abs().max())
+    print(f"GAR-8B full depth f32 HIP vs oracle: max|dlogit| / max|logit| = {err:.3e}")
+    assert o32.sequences[:, :2].cpu().tolist() == ref_seq.tolist()
+    assert err <= FULL_DEPTH_8B_F32_TOL, err
+    seq32, lg32 = o32.sequences.clone(), o32.logits.cpu()
+    from parity_util import discrimination_stats
+    distinct, repeats, rel_margin = discrimination_stats(seq32[0].tolist(), lg32[0])
+    print(f"GAR-8B full depth f32 caption: {distinct} distinct of {NT} tokens, {repeats} immediate repeats, min top-2 "
+          f"margin {rel_margin:.2e} x max|logit|")
+    del m32, o32
+    torch.cuda.empty_cache()
+    sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in s.items()}
+    m16 = GARModel(cfg, W, torch.bfloat16)
+    del W
+    o16 = m16.generate(**sb, max_new_tokens=NT, return_logits=True, forced_tokens=seq32)
+    lg16 = o16.logits.cpu()
+    rel = [_rel_l2(lg16[:, j], lg32[:, j]) for j in range(NT)]
+    agree = (o16.sequences == seq32)[0].cpu()
+    rate = float(agree.float().mean())
+    max_err = float((lg16 - lg32).abs().max())
+    top2 = lg32.topk(2, -1).values[0]
+    margins = (top2[:, 0] - top2[:, 1])
+    print(f"GAR-8B full depth bf16 vs f32 (teacher forced, {NT} tokens): top-1 agreement {rate:.3f}, first-token rel-L2 "
+          f"{rel[0]:.3e}, worst rel-L2 {max(rel):.3e}, max|dlogit| {max_err:.3e}, min f32 margin {float(margins.min()):.3e}")
+    assert max(rel) < FULL_DEPTH_8B_BF16_REL_L2, max(rel)
+    for j in (~agree).nonzero().flatten().tolist():
+        assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
+    free_g = m16.generate(**sb, max_new_tokens=8)
+    free_e = m16.generate(**sb, max_new_tokens=8, use_graph=False)
+    assert torch.equal(free_g.sequences, free_e.sequences)
+
+
+def test_bf16_decode_above_64_sequences(tiny):
+    """more than 64 sequences per step exceed the split-K `down` schedule (M <= 64 rows) — generate must
+    fall back to gemm(EPI_RES) + rmsnorm instead of raising on the first decode step. 65 rows in bf16, teacher-forced on
+    the f32 HIP run of the same batch: per-step logits within the bf16 tolerance, rows of the same sample identical."""
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    ss = [_sample(cfg, proc, i) for i in (3, 4, 6, 7)]
+    order = [i % 4 for i in range(65)]
+
+    def batch(dt):
+        return dict(input_ids=torch.cat([ss[i]["input_ids"] for i in order]),
+                    pixel_values=torch.cat([ss[i]["pixel_values"] for i in order]).to(dt),
+                    global_mask_values=torch.cat([ss[i]["global_mask_values"] for i in order]).to(dt),
+                    bboxes=[ss[i]["bboxes"][0] for i in order],
+                    aspect_ratios=torch.cat([ss[i]["aspect_ratios"] for i in order]))
+    n = 5
+    r32 = GARModel(cfg, W, torch.float32).generate(**batch(torch.float32), max_new_tokens=n, return_logits=True)
+    m = GARModel(cfg, W, torch.bfloat16)
+    out = m.generate(**batch(torch.bfloat16), max_new_tokens=n, return_logits=True, forced_tokens=r32.sequences)
+    assert "down_partial" not in m._ws[("decode", 65)]
+    lg = out.logits.cpu()
+    assert torch.isfinite(lg).all()
+    for j in range(n):
+        assert _rel_l2(out.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
+    for r in range(4, 65):
+        assert torch.equal(lg[r], lg[r % 4]), r

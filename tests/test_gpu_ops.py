@@ -508,6 +508,78 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     assert counters.tolist() == [S + 2, S + 3]
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd", [64, 128])
+def test_llm_left_padded_batch_attention(dev, dt, hd):
+    """A LEFT-padded batch (HF generation's layout for prompts of different lengths; the reference forwards
+    attention_mask, modeling_gar.py:418-426): `left_pad` shifts the RoPE positions, `kv_start` hides the padding keys in
+    the causal prefill and in the decode step (split-KV ranges start at kv_start). Every sequence's real rows must equal
+    the same sequence run alone and unpadded; pads of 0, inside a tile, exactly one tile, and more than a 128-row q block."""
+    from gar_amd import ops
+    from oracle import gar_oracle as O
+    S, Hq, Hkv = 333, 4, 2
+    pads = [0, 37, 64, 150, 301]
+    B = len(pads)
+    Smax = (S + 8 + 63) // 64 * 64
+    Wd = (Hq + 2 * Hkv) * hd
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = pos[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    scale = (hd ** -0.5) * 1.4426950408889634
+    rep = Hq // Hkv
+
+    def ref_qkv(x, p0):                       # x [1, Sx, Wd] of ONE sequence at positions p0 ..
+        Sx = x.shape[1]
+        xq = x[..., :Hq * hd].view(1, Sx, Hq, hd).transpose(1, 2)
+        xk = x[..., Hq * hd:(Hq + Hkv) * hd].view(1, Sx, Hkv, hd).transpose(1, 2)
+        xv = x[..., (Hq + Hkv) * hd:].view(1, Sx, Hkv, hd).transpose(1, 2)
+        c = torch.cat([cos, cos], -1)[p0:p0 + Sx]
+        s_ = torch.cat([sin, sin], -1)[p0:p0 + Sx]
+        return xq * c + O._rotate_half(xq) * s_, xk * c + O._rotate_half(xk) * s_, xv
+
+    qkv = q(rnd(B, S, Wd, seed=41), dt)
+    Spad = (S + 63) // 64 * 64
+    Kc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
+    Vtc = torch.zeros(B, Hkv, hd, Smax, dtype=dt, device=dev)
+    Q = torch.empty(B, Hq, Spad, hd, dtype=dt, device=dev)
+    out = torch.full((B * S, Hq * hd), float("nan"), dtype=dt, device=dev)
+    lp = torch.tensor(pads, dtype=torch.int32, device=dev)
+    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax,
+                     0, None, scale, left_pad=lp)
+    ops.attention(Q, Kc, Vtc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp)
+    assert torch.isfinite(out.float()).all()               # padding rows too: they flow through the following GEMMs
+    outv = out.view(B, S, Hq * hd)
+    refs = []
+    for b, pd in enumerate(pads):
+        rq, rk, rv = ref_qkv(qkv[b:b + 1, pd:], 0)
+        ref = _attn_ref(rq, rk.repeat_interleave(rep, 1), rv.repeat_interleave(rep, 1), True, 0)
+        close(outv[b, pd:], ref.transpose(1, 2).reshape(S - pd, Hq * hd), dt, extra=2.0)
+        close(Kc[b, :, pd:S], rk[0], dt)
+        refs.append(([rk], [rv]))
+    counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
+    Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
+    for step in range(2):
+        x1 = q(rnd(B, 1, Wd, seed=43 + step), dt)
+        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vtc, B, 1, 1, Hq, Hkv, hd, Smax,
+                         0, counters[0:1], scale, left_pad=lp)
+        outs = []
+        for nsplit in (1, 3, 16):
+            ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, nsplit), dtype=torch.uint8, device=dev)
+            o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
+            ops.attention_decode(Q1, Kc, Vtc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws, kv_start=lp)
+            outs.append(o2)
+        ops.counter_add(counters, 1)
+        for b, pd in enumerate(pads):
+            q1, k1, v1 = ref_qkv(x1[b:b + 1], S - pd + step)
+            refs[b][0].append(k1)
+            refs[b][1].append(v1)
+            kk, vv = torch.cat(refs[b][0], 2), torch.cat(refs[b][1], 2)
+            r1 = _attn_ref(q1, kk.repeat_interleave(rep, 1), vv.repeat_interleave(rep, 1), False, 0)
+            for o2 in outs:
+                close(o2[b:b + 1], r1.transpose(1, 2).reshape(1, Hq * hd), dt, extra=2.0)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def test_placeholder_scan_and_assemble(dev):
     from gar_amd import ops

@@ -38,6 +38,26 @@ def test_llama_against_transformers(golden_dir):
         assert seq.tolist() == g["sequences"].tolist()
 
 
+def test_llama_left_padded_batch_against_transformers(golden_dir):
+    """attention_mask of a left-padded batch (what GARModel.generate forwards, modeling_gar.py:418-426): the oracle's
+    tokens and per-step logits equal transformers' generate on the same padded batch, and every padded row reproduces its
+    own unpadded run."""
+    g0 = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    g = np.load(os.path.join(golden_dir, "llama_tiny_padded.npz"))
+    W = {k[2:]: torch.from_numpy(g0[k]) for k in g0.files if k.startswith("W:")}
+    t = _tcfg()
+    emb, mask = torch.from_numpy(g["inputs_embeds"]), torch.from_numpy(g["attention_mask"])
+    seq, logits = O.greedy_generate(emb, W, t, max_new_tokens=10, return_logits=True, attention_mask=mask)
+    assert seq.tolist() == g["sequences"].tolist()
+    ref = torch.from_numpy(g["scores"])
+    assert float((logits - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5
+    assert g["sequences"].tolist() == g["single_sequences"].tolist()
+    for b in range(3):
+        n = int(mask[b].sum())
+        one = O.greedy_generate(emb[b:b + 1, emb.shape[1] - n:], W, t, max_new_tokens=10)
+        assert one[0].tolist() == seq[b].tolist()
+
+
 def test_llama3_inv_freq_real_dims(golden_dir):
     g = np.load(os.path.join(golden_dir, "llama_inv_freq.npz"))
     a = O.llama_inv_freq(_tcfg(head_dim=64))

@@ -246,12 +246,17 @@ def test_loader_refuses_tensors_it_would_silently_drop():
     c2.mllm_config.vision_config.model_args["use_post_transformer_norm"] = True
     with pytest.raises(ValueError, match="use_post_transformer_norm"):
         normalize_checkpoint(c2, W)
-    # an untied head in the checkpoint wins over tie_word_embeddings=True in (or defaulted by) the config
+    # a head that differs from the embedding under a config that ties them is refused (HF would discard the head); with
+    # tie_word_embeddings=False it is the head
     c3 = GARConfig.tiny()
     assert c3.mllm_config.text_config.tie_word_embeddings
     head = torch.randn_like(W[LM + "embed_tokens.weight"])
-    W3 = normalize_checkpoint(c3, {**W, "mllm.lm_head.weight": head})
-    assert not c3.mllm_config.text_config.tie_word_embeddings and W3["mllm.lm_head.weight"] is head
+    with pytest.raises(ValueError, match="tie_word_embeddings"):
+        normalize_checkpoint(c3, {**W, "mllm.lm_head.weight": head})
+    c3.mllm_config.text_config.tie_word_embeddings = False
+    assert normalize_checkpoint(c3, {**W, "mllm.lm_head.weight": head})["mllm.lm_head.weight"] is head
+    # fc_norm.* (timm forward_head only) is ignored, not refused
+    normalize_checkpoint(GARConfig.tiny(), {**W, VT + "fc_norm.weight": torch.ones(D), VT + "fc_norm.bias": torch.zeros(D)})
     c4 = GARConfig.tiny()
     normalize_checkpoint(c4, {**W, "mllm.lm_head.weight": W[LM + "embed_tokens.weight"].clone()})
     assert c4.mllm_config.text_config.tie_word_embeddings

@@ -8,6 +8,8 @@ oracle (oracle/gar_oracle.py) and the host logic (gar_amd.processing / gar_amd.e
 Fixtures written:
   llama_tiny.npz        transformers LlamaForCausalLM (eager, fp32): logits of a prefill + greedy tokens from
                         inputs_embeds, llama3 rope scaling, GQA, tied head          -> pins oracle.llama_* / greedy
+  llama_tiny_padded.npz a left-padded batch (23 / 17 / 9 embeddings) through the same model's generate(inputs_embeds=,
+                        attention_mask=): tokens + per-step scores                   -> pins the oracle's attention_mask path
   projector_tiny.npz    transformers PerceptionLMMultiModalProjector (+AdaptiveAvgPooling) -> pins projector_forward
   torch_ops.npz         torch conv2d / layer_norm / SDPA / GELU building blocks the ViT restatement uses
   ref_helpers.json      outputs of the reference's own pure-Python helpers executed here:
@@ -93,6 +95,42 @@ def golden_llama():
         extra["inv_freq_" + name] = ROPE_INIT_FUNCTIONS["llama3"](c, "cpu")[0].numpy()
     np.savez_compressed(os.path.join(OUT, "llama_inv_freq.npz"), **extra)
     print("llama_tiny: tokens", gen.sequences.tolist())
+
+
+def golden_llama_padded():
+    """A LEFT-PADDED batch through transformers' LlamaForCausalLM.generate(inputs_embeds=, attention_mask=) — the call
+    GARModel.generate ends in (modeling_gar.py:418-426) — on the model of llama_tiny.npz: three prompts of 23 / 17 / 9
+    embeddings padded to 23, 10 greedy tokens, per-step scores. Pins the oracle's attention_mask handling (position ids
+    from the mask, padding keys hidden)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    g = np.load(os.path.join(OUT, "llama_tiny.npz"))
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=64, vocab_size=512, rms_norm_eps=1e-5, rope_theta=500000.0,
+                      rope_scaling={"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                    "original_max_position_embeddings": 8192, "rope_type": "llama3"},
+                      max_position_embeddings=131072, tie_word_embeddings=True, attention_bias=False,
+                      mlp_bias=False, attn_implementation="eager")
+    m = LlamaForCausalLM(cfg).eval().to(torch.float32)
+    sd = {"model." + k[2:][len("mllm.model.language_model."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("W:")}
+    sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    m.load_state_dict(sd)
+    torch.manual_seed(7)
+    S, lens = 23, [23, 17, 9]
+    emb = torch.randn(3, S, 128)
+    mask = torch.zeros(3, S, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, S - n:] = 1
+    with torch.no_grad():
+        gen = m.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=10, do_sample=False, use_cache=True,
+                         return_dict_in_generate=True, output_scores=True, pad_token_id=0, eos_token_id=None)
+        # the same prompts one at a time, unpadded: what a padded row must reproduce
+        singles = [m.generate(inputs_embeds=emb[b:b + 1, S - n:], attention_mask=torch.ones(1, n, dtype=torch.long),
+                              max_new_tokens=10, do_sample=False, use_cache=True, return_dict_in_generate=True,
+                              pad_token_id=0, eos_token_id=None).sequences[0] for b, n in enumerate(lens)]
+    np.savez_compressed(os.path.join(OUT, "llama_tiny_padded.npz"), inputs_embeds=emb.numpy(), attention_mask=mask.numpy(),
+                        sequences=gen.sequences.numpy(), scores=torch.stack(gen.scores, 1).numpy(),
+                        single_sequences=torch.stack(singles).numpy())
+    print("llama_tiny_padded: tokens", gen.sequences.tolist(), "singles", torch.stack(singles).tolist())
 
 
 def golden_projector():
@@ -255,6 +293,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_rle_samples()
     golden_llama()
+    golden_llama_padded()
     golden_projector()
     golden_torch_ops()
     golden_ref_helpers()
