@@ -19,7 +19,7 @@
 // attention_bf16.hip: DMA-staged bf16 kernel (default for bf16); false -> use the register-staged kernel below
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
-                          const int32_t* kv_start, hipStream_t s);
+                          const int32_t* kv_start, int kv_prefix, hipStream_t s);
 
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
@@ -406,7 +406,7 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
                   "attention: head_dim %d not built (64, 128; 96 in bf16 only)", hd);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GAR_BF16 &&
-        gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 0, kv_start, s)) {
+        gar_attn_bf16_v2_try(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 0, kv_start, 0, s)) {
         GAR_CHECK_LAUNCH();
         return GAR_OK;
     }
@@ -422,15 +422,17 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
 // bf16, head_dim 64 / 96 / 128; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
 extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
                                   int hd, int q_len, int q_pad, int kv_len, int kv_stride, int causal,
-                                  const int32_t* kv_len_dev, const int32_t* kv_start, gar_stream_t stream) {
+                                  const int32_t* kv_len_dev, const int32_t* kv_start, int kv_prefix, gar_stream_t stream) {
     GAR_CHECK_ARG(Q && K && V && O, "attention_vrow: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_vrow: bad heads %d/%d", Hq, Hkv);
     GAR_CHECK_ARG(q_len > 0 && q_pad >= q_len && kv_stride % 64 == 0, "attention_vrow: bad lengths");
     GAR_CHECK_ARG(kv_len_dev || (kv_len > 0 && kv_len <= kv_stride && (!causal || kv_len >= q_len)),
                   "attention_vrow: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
+    GAR_CHECK_ARG(kv_prefix == 0 || (kv_prefix == 1 && !causal && !kv_len_dev && kv_len > 1),
+                  "attention_vrow: kv_prefix is 0 or 1 (non-causal, kv_len > 1)");
     if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
         !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,
-                              (hipStream_t)stream)) {
+                              kv_prefix, (hipStream_t)stream)) {
         gar_set_error("attention_vrow: built for bf16, head_dim 64 / 96 / 128 (dtype %d, head_dim %d)", dtype, hd);
         return GAR_ERR_UNSUPPORTED;
     }

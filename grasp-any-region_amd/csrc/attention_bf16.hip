@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
                                                               int kv_stride, const int32_t* __restrict__ kv_len_dev,
-                                                              const int32_t* __restrict__ kv_start) {
+                                                              const int32_t* __restrict__ kv_start, int kv_prefix) {
     // head_dim 96 (PE-G/14): K rows are 192 B in HBM; the LDS image keeps the 256-B row pitch of head_dim 128 (a
     // 4-row x 256-B DMA piece per instruction; the 64 bytes past a row's 12 real chunks are filled with a repeat of
     // chunk 11 and never read), so the fragment reads use the conflict-free head_dim-128 swizzle
@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     constexpr int KI = KT / 4096;               // K DMA instructions per wave per tile (1 KiB each)
     constexpr int VI = VT / 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | Vt]
-    const int kv_len = kv_len_dev ? kv_len_dev[0] : kv_len_arg;
+    // kv_prefix = 1 (non-causal, row-major V: the ViT with its cls token): key / value row 0 is folded into the INITIAL
+    // softmax state instead of riding in a kv tile — m0 = q . k0, l0 = 1, O0 = v0 — and the tiles cover rows 1 .. kv_len - 1:
+    // 1025 keys are 16 full tiles instead of 17 with one live column in the last (and no masked tile at all).
+    const int PFX = (!CAUSAL && VROW) ? kv_prefix : 0;
+    const int kv_len = (kv_len_dev ? kv_len_dev[0] : kv_len_arg) - PFX;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     auto stage = [&](int t, int buf) {
         char* ks = smem + buf * (KT + VT);
         char* vs = ks + KT;
-        const unsigned kbase = (unsigned)t * 64u * KRS_G;               // 64 kv rows per tile
-        const unsigned vbase = VROW ? (unsigned)t * 64u * KRS_G : (unsigned)t * 128u;     // 64 kv rows / 64 kv columns
+        const unsigned kbase = ((unsigned)t * 64u + (unsigned)PFX) * KRS_G;               // 64 kv rows per tile
+        const unsigned vbase = VROW ? ((unsigned)t * 64u + (unsigned)PFX) * KRS_G : (unsigned)t * 128u;     // 64 kv rows / 64 kv columns
 #pragma unroll
         for (int i = 0; i < KI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
@@ -141,6 +145,29 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    if (PFX) {
+        // s0 = q . k0 (q carries scale * log2e): this lane holds dims 16 kd + 8 h .. + 8 of its query row
+        float part = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + kd * 16 + h * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                part = __builtin_fmaf(bf2f((bf16_t)qf[kd][e]), bf2f((bf16_t)kf[e]), part);
+        }
+        m_run = part + __shfl_xor(part, 32, 64);
+        l_run = h == 0 ? 1.0f : 0.f;                // the two halves' l are added at the end
+        // O0 = v0: register r of row block d is d index 32 d + (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v4[4];
+                ld4(Vp + d * 32 + g * 8 + h * 4, v4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[d][g * 4 + r] = v4[r];
+            }
+    }
     // The QK^T accumulator chains start from -m (the running max the scores are measured against) instead of 0: the MFMA
     // delivers s - m and the softmax needs no subtraction — 32 VALU instructions fewer per kv tile in a loop whose SIMD
     // time is matrix pipe time plus most of the VALU issue time (tools/coissue_probe.hip, profiles/r2_attention_timeline.txt).
@@ -153,6 +180,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #endif
     constexpr bool NEGM = (HD == 64 && (ATTN_NEGM_SET & 1)) || (HD == 128 && (ATTN_NEGM_SET & 2)) || (HD == 96 && (ATTN_NEGM_SET & 4));
     f32x16 negm = zero16_c();
+    if (PFX && NEGM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+    }
 
     // Left-padded batch (CAUSAL only; kv_start[b] = first real position of sequence b, NULL = 0): a key is visible iff
     // kv_lo <= kv <= max(q + coff, kv_lo). Rows in front of kv_lo (padding queries, never read) see exactly key kv_lo, so every
@@ -395,14 +426,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 // vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
-                          const int32_t* kv_start, hipStream_t s) {
+                          const int32_t* kv_start, int kv_prefix, hipStream_t s) {
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
     const int kt = 64 * (hd == 64 ? 128 : 256);
     const int lds = 2 * (kt + (vrow ? kt : hd * 128));
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
-                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start)
+                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix)
     if (hd == 64) {
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }

@@ -46,12 +46,6 @@
 #define PP_DIAG_L2STORE false
 #endif
 
-#ifdef PP_DIRECT_EPI      /* diagnostic: 16-byte stores straight from the fragments (16 rows x 64 B per instruction), no LDS pass */
-#define PP_DIAG_DIRECT (EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_PATCH_POS)
-#else
-#define PP_DIAG_DIRECT false
-#endif
-
 #define PBM 256
 #define PBK 64
 #define PHALF (128 * 128)             // 16 KiB: 128 rows x 64 bf16
@@ -101,7 +95,11 @@ __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
     const float u = __builtin_fmaf(x, 128.0f, 1024.0f);
     const float fi = __builtin_floorf(__builtin_amdgcn_fmed3f(u, 0.0f, 2047.0f));
     const float2 e = *reinterpret_cast<const float2*>(lut + ((int)fi << 3));
-    return __builtin_fmaf(e.y, u - fi, e.x);
+    // one v_fma_f32 per element, pinned: left to itself the compiler pairs two elements into a v_pk_fma_f32 and pays three
+    // v_mov to shuffle (value, slope) of the two table entries into operand pairs — 4 instructions where 2 do
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(u - fi), "v"(e.x));
+    return r;
 }
 
 // Patch gather (GATHER, GAR_EPI_PATCH_POS only — gar_patch_embed): the A operand is not a matrix in HBM but the image
@@ -198,6 +196,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     const int tgm = tile_group_m(p.K, tiles_n);
     tile_of(v, total, tiles_m, tiles_n, tm, tn, tgm);
     int m0 = tm * PBM, n0 = tn * PBM;
+    // Bias epilogues (PERM layout): the accumulator chains start from the bias instead of 0 — the 128 adds per lane and tile,
+    // and the epilogue's wait for its own bias load (s_waitcnt vmcnt(0) in front of the first store: in-order counter),
+    // disappear. A lane's fragment columns are the same for all eight m-tiles: 16 values = two 16-byte loads per tile,
+    // fetched one tile ahead. fp32 sum order changes from (products) + b to b + (products): one rounding of the bf16 result.
+    constexpr bool BIAS_INIT = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES ||
+                               EPI == GAR_EPI_QKV_ROPE;
+    u32x4 bias_cur[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    auto load_bias = [&](int n0_, u32x4 (&b)[2]) {
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            const int nb = n0_ + wn * 64 + jq * 32 + fq * 8;
+            b[jq] = (p.bias && nb < p.N) ? *reinterpret_cast<const u32x4*>((const bf16_t*)p.bias + nb) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    if (BIAS_INIT) load_bias(n0, bias_cur);
     stage_A(m0, 0, smem);
     stage_W(n0, 0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -353,7 +366,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #endif
     auto epilogue_lds = [&](char* E) {
         constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;
-        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES || QKV;
         constexpr bool HAS_RES = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES;
         // a thread always serves the same 8-column group (cg = tid & 31): bias / LayerScale are loaded once per tile
         // (opaque per call: otherwise the compiler hoists the sixteen 64-bit row addresses and the LDS offsets out of the
@@ -362,13 +374,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         asm volatile("" : "+v"(cg), "+v"(r0), "+v"(frow_e), "+v"(fq_e));
         const int n = n0 + cg * 8;
         const bool nok = n < p.N;
-        float bias8[8], gam8[8];
+        float gam8[8];
         // QKV_ROPE: this thread's 8 columns are dims d..d+7 of head h of q (part 0), k (1) or v (2)
         const int Da = p.qkv_heads * p.qkv_head_dim;
         const int part = QKV ? n / Da : 0;
         const int nn = QKV ? n - part * Da : 0;
         const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
-        if (HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
         auto write_chunk = [&](int c) {        // the owning wave row's fragments of 64-row chunk c -> E (fp32)
             if (wm == (c >> 1)) {
@@ -428,10 +439,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 const f32x4 a = ra4[k], b = rb4[k];
                 if (ok[k]) {
                     float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                    if (HAS_BIAS) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] += bias8[e];
-                    }
                     if (EPI == GAR_EPI_BIAS_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = gelu_fast(o[e]);
@@ -499,7 +506,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     auto epilogue_wave = [&](char* E) {
         constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;       // compact sin/cos table only (qkv_cos == NULL)
         constexpr bool DIRECT = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
-        constexpr bool HAS_BIAS = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES || QKV;
         constexpr bool HAS_AUX = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES || EPI == GAR_EPI_PATCH_POS;
         int lane_e = lane, frow_e = frow, fq_e = fq;
         asm volatile("" : "+v"(lane_e), "+v"(frow_e), "+v"(fq_e));             // see epilogue_lds
@@ -507,16 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const int rr = lane_e >> 3, ch = lane_e & 7;      // row side: rows rr and 8 + rr of a 16-row step, 8 columns ch*8..
         const int n = n0 + wn * 64 + ch * 8;
         const bool nok = n < p.N;
-        u32x4 biasp[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};      // DIRECT: this lane's fragment columns
-        float bias8[8], gam8[8];                                              // otherwise: this lane's row-side columns
-        if (DIRECT && HAS_BIAS) {
-#pragma unroll
-            for (int jq = 0; jq < 2; ++jq) {
-                const int nb = n0 + wn * 64 + jq * 32 + fq_e * 8;
-                if (nb < p.N) biasp[jq] = *reinterpret_cast<const u32x4*>((const bf16_t*)p.bias + nb);
-            }
-        }
-        if (!DIRECT && HAS_BIAS && nok) ld8((const bf16_t*)p.bias + n, bias8);
+        float gam8[8];                                   // LayerScale of this lane's row-side columns (the bias is in the accumulators)
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
         // destination element offset and row-dependent load of row-side slot (i, t)
         auto row_of = [&](int i, int t) { return m0 + wm * 128 + i * 16 + t * 8 + rr; };
@@ -606,13 +603,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 for (int jq = 0; jq < 2; ++jq) {
                     float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
                                   acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
-                    if (HAS_BIAS) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[2 * e] += __uint_as_float(biasp[jq][e] << 16);
-                            o[2 * e + 1] += __uint_as_float(biasp[jq][e] & 0xffff0000u);
-                        }
-                    }
                     if (EPI == GAR_EPI_BIAS_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = gelu_lut(o[e], glut);
@@ -663,10 +653,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                     const f32x4 a = a2[t], b = b2[t];
                     if (nok && m < p.M) {
                         float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                        if (HAS_BIAS) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] += bias8[e];
-                        }
                         if (HAS_AUX) {
                             const u32x4 w = aux[i % (AH + 1)][t];
 #pragma unroll
@@ -719,10 +705,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 
     int sidx = 0;
     while (true) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int vn = v + gridDim.x;
         const bool has_next = vn < total;
         int m0n = 0, n0n = 0;
@@ -731,6 +713,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             tile_of(vn, total, tiles_m, tiles_n, tmn, tnn, tgm);
             m0n = tmn * PBM;
             n0n = tnn * PBM;
+        }
+        if (BIAS_INIT) {
+            // acc[i][j][r] is column 32 (j >> 1) + 8 fq + 4 (j & 1) + r of the wave's strip: element 4 (j & 1) + r of bias_cur[j >> 1]
+            float bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned w = bias_cur[j >> 1][((j & 1) * 4 + r) >> 1];
+                    bv[j][r] = (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j][0], bv[j][1], bv[j][2], bv[j][3]};
+            // the NEXT tile's bias: issued here, older than every DMA of this tile, so the main loop's in-order vmcnt(n)
+            // waits cover it long before it is used at the top of the next iteration
+            load_bias(n0n, bias_cur);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // loop-carried, prepared at the end of the previous K tile under its last MFMAs (the first interval of a K tile is
         // the longest: nothing but the reads and one DMA should sit between the barrier and the next barrier)
@@ -871,11 +876,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
         constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
-        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && !PP_DIAG_DIRECT && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
+        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
         } else {
             if (wm == 0) __builtin_amdgcn_s_barrier();
-            if (PERM && LDS_EPI && !PP_DIAG_NOSTORE && !PP_DIAG_DIRECT) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
+            if (PERM && LDS_EPI && !PP_DIAG_NOSTORE) epilogue_lds(smem + (sidx ^ 1) * PSTAGE);
             else epilogue();
         }
 #if PP_TIMELINE == 4

@@ -94,6 +94,7 @@ def _on_model_device(fn):
 
 
 class GARModel:
+    VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
     FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
@@ -373,7 +374,9 @@ class GARModel:
                 ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
                 ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
             if Vr is not None:      # v left the qkv GEMM head-major like k: the attention transposes it on its LDS reads
-                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True)
+                # the cls key (row 0) enters through the softmax's initial state: 1 + 1024 keys are 16 kv tiles, not 17
+                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True,
+                              kv_prefix=self.npt if self.VIT_CLS_KEY_FOLD and N > 1 else 0)
             else:
                 ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
             ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])

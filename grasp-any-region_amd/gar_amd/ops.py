@@ -251,13 +251,14 @@ def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0,
 
 
 def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None,
-              v_row_major: bool = False, kv_start=None):
+              v_row_major: bool = False, kv_start=None, kv_prefix: int = 0):
     """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout; bf16, head_dim 64) instead of its transpose.
-    ``kv_start`` int32 [B] (device) or None: first visible kv row per sequence (left-padded batch)."""
+    ``kv_start`` int32 [B] (device) or None: first visible kv row per sequence (left-padded batch).
+    ``kv_prefix`` = 1 (v_row_major, non-causal): kv row 0 is folded into the softmax's initial state (ViT cls token)."""
     if v_row_major:
         check(lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
-                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()),
-              "gar_attention_vrow")
+                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), int(kv_prefix),
+                                       stream()), "gar_attention_vrow")
         return
     check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
                               kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention")

@@ -176,10 +176,13 @@ int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void*
  * operand is formed by gfx950's transposing LDS read (ds_read_b64_tr_b16), so timm AttentionRope's v needs no transpose
  * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64 /
  * 96 / 128;
- * GAR_ERR_UNSUPPORTED (nothing launched) otherwise. */
+ * GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
+ * kv_prefix = 1 (non-causal only): key / value row 0 — the ViT's cls token — enters through the initial softmax state
+ * (m0 = q.k0, l0 = 1, O0 = v0) and the kv tiles cover rows 1 .. kv_len - 1: 1 + 1024 keys are 16 tiles, not 17. Same
+ * result up to the fp32 summation order. */
 int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd,
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
-                       const int32_t* kv_start, gar_stream_t stream);
+                       const int32_t* kv_start, int kv_prefix, gar_stream_t stream);
 
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
  * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / Vt.

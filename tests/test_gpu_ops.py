@@ -378,6 +378,12 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
         out2 = torch.empty_like(out)
         ops.attention(Q, K, Vr, out2, T, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True)
         assert torch.equal(out2, out)
+        # kv_prefix = 1: key / value row 0 (the cls token) enters through the initial softmax state (m0 = q.k0, l0 = 1,
+        # O0 = v0) and the tiles cover rows 1 ..: 1 + 1024 keys are 16 tiles. Same softmax, another summation order.
+        out3 = torch.full_like(out, float("nan"))
+        ops.attention(Q, K, Vr, out3, T, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True, kv_prefix=1)
+        close(out3, ref, dt, extra=2.0)
+        close(out3, out.float(), dt, extra=0.5)
         outc, outc2 = torch.empty_like(out), torch.empty_like(out)
         ops.attention(Q, K, Vt, outc, T, H, H, hd, N, Npad, N, Npad, causal=True)
         ops.attention(Q, K, Vr, outc2, T, H, H, hd, N, Npad, N, Npad, causal=True, v_row_major=True)
@@ -429,6 +435,19 @@ def test_attention_lazy_max_redo_path(dev, hd, causal, profile):
         out2 = torch.empty_like(out)
         ops.attention(Q, K, Vt.transpose(2, 3).contiguous(), out2, B, H, H, hd, n, n, n, n, causal=causal, v_row_major=True)
         assert torch.equal(out2, out)
+    if not causal:
+        # key row 0 through the initial softmax state (kv_prefix = 1): the standing max then starts at q.k0, which the
+        # profile outgrows (or undercuts) like any first tile; also with a k0 that dominates / is negligible
+        Vr = Vt.transpose(2, 3).contiguous()
+        for k0_scale in (1.0, 60.0, -60.0):
+            K2 = K.clone()
+            K2[:, :, 0] = (K[:, :, 0].float() * k0_scale).to(dt)
+            s3 = (Q.double().cpu() @ K2.double().cpu().transpose(-1, -2)) * 0.6931471805599453
+            ref3 = (torch.softmax(s3, -1) @ Vr.double().cpu()).transpose(1, 2).reshape(B * n, H * hd)
+            out3 = torch.full_like(out, float("nan"))
+            ops.attention(Q, K2, Vr, out3, B, H, H, hd, n, n, n, n, causal=False, v_row_major=True, kv_prefix=1)
+            assert torch.isfinite(out3.float()).all()
+            close(out3, ref3, dt, extra=2.0)
 
 
 def test_attention_vrow_refuses_f32(dev):
