@@ -293,6 +293,60 @@ __device__ __forceinline__ void roi_replay_row(const T* feats, T* embeds, int he
         return feats + (rank_pos ? (int64_t)rank_pos[rank] : rank) * C;
     };
     T* dst = embeds + (int64_t)row * C;
+    // Common case — a bin no larger than a map cell, so both samples of an axis share their (lo, hi) pair: 2 x 2 distinct
+    // cells. All channel passes of the row (C / cstride: 4 at C = 2048, 8 at C = 4096) then issue their loads together,
+    // 4 x 16 bytes per lane and pass, before the first blend — a wave has one dependent round trip instead of one per pass
+    // (a CU holds 16 waves, so the memory-level parallelism of this latency-bound kernel has to come from inside the wave:
+    // 128 jobs x 256 bins at C = 4096 ran at 0.38 of HBM with one pass in flight). Same cells, same arithmetic order.
+    if (Y[2] == Y[0] && Y[3] == Y[1] && X[2] == X[0] && X[3] == X[1]) {
+        const T* p00 = cell(Y[0], X[0]);
+        const T* p01 = cell(Y[0], X[1]);
+        const T* p10 = cell(Y[1], X[0]);
+        const T* p11 = cell(Y[1], X[1]);
+        constexpr int UN = 4;
+        for (int cb = c0; cb < C; cb += UN * cstride) {
+            Raw8<T> q[UN][4];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int c = cb + u * cstride;
+                if (c < C) {
+                    q[u][0].load(p00 + c);
+                    q[u][1].load(p01 + c);
+                    q[u][2].load(p10 + c);
+                    q[u][3].load(p11 + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int c = cb + u * cstride;
+                if (c < C) {
+                    float v1[8], v2[8], v3[8], v4[8], acc[8];
+                    q[u][0].get(v1);
+                    q[u][1].get(v2);
+                    q[u][2].get(v3);
+                    q[u][3].get(v4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int iy = 0; iy < G; ++iy) {
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            const bool valid = ay[iy].valid && ax[ix].valid;
+                            const float w1 = valid ? ay[iy].h * ax[ix].h : 0.f, w2 = valid ? ay[iy].h * ax[ix].l : 0.f;
+                            const float w3 = valid ? ay[iy].l * ax[ix].h : 0.f, w4 = valid ? ay[iy].l * ax[ix].l : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                acc[e] = acc[e] + (((w1 * v1[e] + w2 * v2[e]) + w3 * v3[e]) + w4 * v4[e]);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = acc[e] / count;
+                    st8(dst + c, acc);
+                }
+            }
+        }
+        return;
+    }
     for (int c = c0; c < C; c += cstride) {
         Raw8<T> g[4][4];
 #pragma unroll

@@ -659,7 +659,10 @@ def test_config0_demo_asset_f32_parity(golden_dir, max_num_tiles, canvas):
 
 
 FULL_DEPTH_8B_F32_TOL = 2e-4
-FULL_DEPTH_8B_BF16_REL_L2 = 8e-2     # 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: 6e-2); measured value printed
+# 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: bound 6e-2, measured 4.8e-2). Measured here: first token 7.1e-2 ... 7.2e-2,
+# worst of 32 steps 7.7e-2 ... 8.0e-2 across builds that differ only in an fp32 summation order (bias as the accumulator
+# start instead of an epilogue add): the same 25 % margin over the measured value as the GAR-1B bound
+FULL_DEPTH_8B_BF16_REL_L2 = 1.0e-1
 
 
 def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():

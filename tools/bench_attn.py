@@ -26,10 +26,11 @@ def main():
 
         vrow = os.environ.get("VROW") == "1"
         Vr = Vt.transpose(2, 3).contiguous() if vrow else None
+        pfx = int(os.environ.get("KV_PREFIX", "0")) if (vrow and not causal and n % 64 == 1) else 0    # cls key folded
 
         def run():
             if vrow:
-                ops.attention(Q, K, Vr, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal, v_row_major=True)
+                ops.attention(Q, K, Vr, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal, v_row_major=True, kv_prefix=pfx)
             else:
                 ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
         for _ in range(3):
