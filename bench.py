@@ -342,7 +342,7 @@ def main(argv=None, runtime=None):
                 "algorithmic_bytes_per_launch": nb / cnt, "time_share_of_step": sec / elapsed}
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
         # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/ (newest round first)
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if args.workload == "single" and args.model == "gar_1b" and os.path.exists(pmc):
                 try:

@@ -93,6 +93,76 @@ def _on_model_device(fn):
     return wrapped
 
 
+class _InputEmbeddings:
+    """callable returned by ``get_input_embeddings()``: ids [...] -> rows of embed_tokens [..., C] (gar_embed_lookup)."""
+
+    def __init__(self, model):
+        self._m = model
+        self.weight = model.E
+
+    def __call__(self, input_ids: torch.Tensor) -> torch.Tensor:
+        m = self._m
+        with torch.cuda.device(m.device):
+            ids = input_ids.to(m.device, torch.int64).contiguous()
+            out = torch.empty(*ids.shape, m.E.shape[1], dtype=m.dtype, device=m.device)
+            if ids.numel():
+                ops.embed_lookup(ids.view(-1), m.E, out.view(-1, m.E.shape[1]))
+        return out
+
+
+class _MllmFacade:
+    """``model.mllm`` of the reference's GARModel (modeling_gar.py:47-50): the helper calls its generate() makes
+    (:332-346) for callers that script the stages themselves. Each method is the HIP kernel ``generate`` itself uses
+    (or a pure index view); the reference's own callers in scope never touch them."""
+
+    def __init__(self, model):
+        self._m = model
+        self.config = model.config.mllm_config
+
+    @property
+    def dtype(self):
+        return self._m.dtype
+
+    @property
+    def device(self):
+        return self._m.device
+
+    def get_input_embeddings(self):
+        return _InputEmbeddings(self._m)
+
+    def get_image_features(self, pixel_values, mask_embeds=None, global_mask_values=None, **kw):
+        """modeling_perception_lm.py:239-269. ``mask_embeds`` (the output of the reference's mask_patch_embedding conv) is
+        not an input here — the mask convolution is part of the patch-embed GEMM; pass the processor's
+        ``global_mask_values`` instead."""
+        if mask_embeds is not None:
+            raise hip.GarError("mask_embeds is not taken: the mask convolution runs inside the patch-embed GEMM; pass "
+                               "global_mask_values (the processor's mask tiles) instead")
+        return self._m.get_image_features(pixel_values, global_mask_values)
+
+    def get_placeholder_mask(self, input_ids, inputs_embeds, image_features=None, video_features=None):
+        """(special_image_mask, special_video_mask) expanded to ``inputs_embeds``' shape, with the reference's count check
+        (modeling_perception_lm.py:271-331) — from gar_placeholder_scan's slot table."""
+        m = self._m
+        if input_ids is None:
+            raise hip.GarError("get_placeholder_mask needs input_ids (the embeds-only form of the reference is not built)")
+        with torch.cuda.device(m.device):
+            ids = input_ids.to(m.device, torch.int64).contiguous()
+            B, S = ids.shape
+            masks = []
+            for tok, feats, what in ((self.config.image_token_id, image_features, "Image"),
+                                     (self.config.video_token_id, video_features, "Videos")):
+                slot = torch.empty(B, S, dtype=torch.int32, device=m.device)
+                counts = torch.empty(B, dtype=torch.int32, device=m.device)
+                spans = torch.empty(B, 1, 2, dtype=torch.int32, device=m.device)
+                ops.placeholder_scan(ids, tok, m.crop_ids_dev[:1], slot, counts, spans)
+                n_tok = int(counts.sum().item())
+                if feats is not None and n_tok * inputs_embeds.shape[-1] != feats.numel():
+                    raise ValueError(f"{what} features and image tokens do not match: tokens: {n_tok}, features "
+                                     f"{feats.numel() // feats.shape[-1]}")
+                masks.append((slot >= 0).unsqueeze(-1).expand_as(inputs_embeds))
+        return masks[0], masks[1]
+
+
 class GARModel:
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
@@ -110,6 +180,7 @@ class GARModel:
         check_weights(config, weights)
         with torch.cuda.device(self.device):
             self._prepare_weights(weights)
+        self.mllm = _MllmFacade(self)
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
         self._llm_lru: List[tuple] = []
@@ -162,6 +233,18 @@ class GARModel:
 
     def eval(self):
         return self
+
+    def get_input_embeddings(self):
+        """modeling_gar.py:67-68"""
+        return _InputEmbeddings(self)
+
+    @staticmethod
+    def _merge(tiles: torch.Tensor, ncw: int, nch: int) -> torch.Tensor:
+        """modeling_gar.py:248-260: [B, nch*ncw, C, th, tw] tiles -> [B, C, nch*th, ncw*tw] image. A pure index permutation;
+        ``generate`` never materialises it (gar_roi_replay indexes the tile layout), kept for callers that want the map."""
+        b, n, c, th, tw = tiles.shape
+        assert n == ncw * nch, f"{ncw * nch} != {n}"
+        return tiles.view(b, nch, ncw, c, th, tw).permute(0, 3, 1, 4, 2, 5).contiguous().view(b, c, nch * th, ncw * tw)
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         return t.to(device=self.device, dtype=self.dtype).contiguous()

@@ -118,6 +118,32 @@ def test_f32_intermediates_tiny(tiny):
     assert torch.equal(emb[0].cpu()[plain], ref_emb[0][plain])
 
 
+def test_mllm_helper_api(tiny):
+    """`model.mllm.*` / `get_input_embeddings` of the reference (modeling_gar.py:64-72,332-346) for callers that script
+    the stages of generate() themselves."""
+    from gar_amd import hip
+    from gar_amd.modeling_gar import GARModel
+    from oracle import gar_oracle as O
+    cfg, W, proc = tiny
+    s = _sample(cfg, proc, 2)
+    m = GARModel(cfg, W, torch.float32)
+    emb = m.mllm.get_input_embeddings()(s["input_ids"])
+    ref = torch.nn.functional.embedding(s["input_ids"], W[O.LM + "embed_tokens.weight"])
+    assert torch.equal(emb.cpu(), ref) and torch.equal(m.get_input_embeddings()(s["input_ids"][0, :7]).cpu(), ref[0, :7])
+    feats = m.mllm.get_image_features(s["pixel_values"], global_mask_values=s["global_mask_values"]).clone()
+    img_mask, vid_mask = m.mllm.get_placeholder_mask(s["input_ids"], emb, image_features=feats)
+    want = (s["input_ids"] == cfg.mllm_config.image_token_id).unsqueeze(-1).expand_as(ref)
+    assert torch.equal(img_mask.cpu(), want) and not bool(vid_mask.any())
+    # masked_scatter with that mask is the oracle's embed_and_scatter (modeling_gar.py:341-346)
+    scattered = emb.masked_scatter(img_mask, feats)
+    want_emb = O.embed_and_scatter(s["input_ids"], W[O.LM + "embed_tokens.weight"], feats.cpu(), cfg.mllm_config.image_token_id)
+    assert torch.equal(scattered.cpu(), want_emb)
+    with pytest.raises(ValueError, match="do not match"):
+        m.mllm.get_placeholder_mask(s["input_ids"], emb, image_features=feats[:-1])
+    with pytest.raises(hip.GarError, match="mask_embeds"):
+        m.mllm.get_image_features(s["pixel_values"], mask_embeds=torch.zeros(1))
+
+
 def test_batch_equals_singles_f32(tiny):
     from gar_amd.modeling_gar import GARModel
     cfg, W, proc = tiny

@@ -123,6 +123,8 @@ def test_merge_matches_reference_index_map(golden_dir):
     merged = O.merge_tiles(tiles, ncw, nch)
     img = torch.arange(C * nch * th * ncw * tw, dtype=torch.float32).view(1, C, nch * th, ncw * tw)
     assert r["roundtrip_equal"] and torch.equal(merged, img)
+    from gar_amd.modeling_gar import GARModel           # the product's _merge (same index map, never used by generate)
+    assert torch.equal(GARModel._merge(tiles, ncw, nch), img)
 
 
 # ---- RoI-align known answers ----------------------------------------------------------------

@@ -27,6 +27,22 @@ def main():
     hip.require_device(0)
     dev, dt = "cuda:0", torch.bfloat16
     P, C, tiles, S, V = 16, 2048, 17, 4718, 128262
+    # video replay (BASELINE configs[4]): GAR-8B width, 8 frames per clip, one 256-row replay per frame on its own P x P map
+    Cv, fr = 4096, 8
+    for n in (16, 64):
+        feats = torch.randn(n * fr, P * P, Cv, device=dev).to(dt)
+        Sv = 4296
+        emb = torch.zeros(n, Sv, Cv, device=dev, dtype=dt)
+        spans = torch.full((n, fr, 2), -1, dtype=torch.int32)
+        for f in range(fr):
+            spans[:, f, 0], spans[:, f, 1] = 100 + 512 * f, 100 + 512 * f + 255
+        spans = spans.to(dev)
+        jobs = ops.roi_jobs_tensor([(b, f, f, 1, 1, 3.1 + f, 5.6, 9.8 + f * 0.5, 13.1, 1.0 / 28) for b in range(n)
+                                    for f in range(fr)], dev)
+        t = timeit(lambda: ops.roi_replay_batched(feats, emb, spans, jobs, fr, fr, P, Cv, Sv))
+        nb = n * fr * (P * P + 16) * Cv * 2
+        print(f"roi_replay_batched video clips={n:3d} ({n * fr} jobs, C={Cv}): {t * 1e6:8.1f} us  {nb / 1e6:7.2f} MB  "
+              f"{nb / t / 1e9:7.1f} GB/s", flush=True)
     for n in (1, 16, 64):
         feats = torch.randn(n * tiles, P * P, C, device=dev).to(dt)
         emb = torch.zeros(n, S, C, device=dev, dtype=dt)
