@@ -352,6 +352,8 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
                           p.N == 3 * p.qkv_heads * p.qkv_head_dim && p.qkv_tokens > 0 && p.M % p.qkv_tokens == 0 &&
                           p.qkv_tokens_pad >= p.qkv_tokens && p.qkv_prefix >= 0 && p.qkv_prefix <= p.qkv_tokens,
                       "gar_gemm: QKV_ROPE args");
+    if (e == GAR_EPI_QKV_ROPE)      // the compact (sin, cos)-pair table goes with the per-wave epilogue, which writes v head-major
+        GAR_CHECK_ARG(p.qkv_cos || p.qkv_v, "gar_gemm: QKV_ROPE with the compact table (qkv_cos == NULL) needs qkv_v");
     if (e == GAR_EPI_PATCH_POS)
         GAR_CHECK_ARG(p.pos && p.tokens_in > 0 && p.tokens_out >= p.tokens_in + p.token_offset && p.N % 4 == 0,
                       "gar_gemm: PATCH_POS args");

@@ -323,21 +323,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
             return;
         }
+        if (EPI == GAR_EPI_SWIGLU) {
+            // 8-byte stores straight from the fragments (gate16 | up16 tile pairs: lane (frow, fq) holds 4 consecutive output
+            // columns of row frow). Per-tile base + one v_mad_u32_u24 per store; the tile GEMM's entry conditions (N % 8 == 0,
+            // ldc % 8 == 0, 16-byte aligned C) make every store aligned and whole, so the generic store's checks are gone.
+            char* const Cw = (char*)p.C + (int64_t)(m0 + wm * 128) * p.ldc * 2;
+            const unsigned ldc2 = (unsigned)p.ldc * 2u;
+            const int m_lim = p.M - (m0 + wm * 128);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int nin = n0 + wn * 64 + jj * 32;                  // wave-uniform
+                if (nin < p.N) {
+                    const unsigned col2 = (unsigned)((nin >> 1) + fq * 4) * 2u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
+                        if (i * 16 + frow < m_lim)
+                            *reinterpret_cast<uint2*>(Cw + ((unsigned)(i * 16 + frow) * ldc2 + col2)) =
+                                make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm * 128 + i * 16 + frow;
             if (m < p.M) {
                 if (EPI == GAR_EPI_SWIGLU) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int nin = n0 + wn * 64 + jj * 32;
-                        if (nin < p.N) {
-                            float o[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
-                            epilogue_store<bf16_t, EPI>(p, m, (nin >> 1) + fq * 4, o);
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int jq = 0; jq < 2; ++jq) {
@@ -536,37 +551,60 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 tok = m - tile * TT;
             }
         };
-        auto dst_off = [&](int m) -> int64_t {
+        // Addresses of slot (i, t). Linear outputs (everything but PATCH_POS / QKV_ROPE): a WAVE-UNIFORM 64-bit base — row
+        // mw + 16 i + 8 t of C / of the residual, scalar arithmetic — plus this lane's 32-bit byte offset (row rr, column n),
+        // so the store / load takes its `saddr` form: ~2 VALU per slot where the per-lane 64-bit m * ld + n chain took 9.
+        // (the base is per TILE — C + mw * ldc — and the slot's row offset (16 i + 8 t) * ld, < 2^24, joins the lane's
+        // offset in one v_mad_u32_u24: no 64-bit arithmetic per slot, scalar or vector)
+        const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u, n2 = (unsigned)(nok ? n : 0) * 2u;
+        char* const Cw = (char*)p.C + (int64_t)mw * p.ldc * 2;
+        const int mwc = min(mw, p.M - 1);                     // the residual is READ for clamped rows at the M tail
+        const char* const Rw = (const char*)p.residual + (int64_t)mwc * p.ldr * 2;
+        const int r_lim = p.M - 1 - mwc;
+        auto dst_ptr = [&](int i, int t, int m) -> bf16_t* {
             if (EPI == GAR_EPI_PATCH_POS) {
                 int tile, tok;
                 split_row(m, tile, tok);
-                return ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
+                return (bf16_t*)p.C + ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
             }
-            if (PP_DIAG_L2STORE) return (int64_t)(m - m0) * p.ldc + (n - n0);     // diagnostic build: L2-resident stores
-            return (int64_t)m * p.ldc + n;
+            if (PP_DIAG_L2STORE) return (bf16_t*)p.C + (int64_t)(m - m0) * p.ldc + (n - n0);     // diagnostic build: L2-resident stores
+            return reinterpret_cast<bf16_t*>(Cw + ((unsigned)(i * 16 + t * 8 + rr) * ldc2 + n2));
         };
         auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional (clamped) so the prefetch ring carries no exec state
-            const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
             if (EPI == GAR_EPI_PATCH_POS) {
+                const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
                 int tile, tk;
                 split_row(m, tile, tk);
                 const int tok = p.token_offset + max(tk, 0);
                 return *reinterpret_cast<const u32x4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + nc);
             }
-            return *reinterpret_cast<const u32x4*>((const bf16_t*)p.residual + (int64_t)m * p.ldr + nc);
+            const int rel = min(i * 16 + t * 8 + rr, r_lim);
+            return *reinterpret_cast<const u32x4*>(Rw + ((unsigned)rel * ldr2 + n2));
         };
         // QKV_ROPE: this lane's 8 columns are dims qd..qd+7 of head qh of q (part 0), k (1) or v (2); the rotation of row
-        // (token) tok needs the four (sin, cos) pairs of those dims: two 16-byte loads, issued one 16-row step ahead
+        // (token) tok needs the four (sin, cos) pairs of those dims: two 16-byte loads, issued one 16-row step ahead.
+        // Branch-free per slot: ONE destination pointer (q / k / v base chosen per lane, all three head-major), rotation by
+        // selects ((sin, cos) = (0, 1) where nothing rotates) and one 16-byte store. The three-armed form this replaces
+        // compiled to a 4-byte + a 12-byte store per slot and ~145 VALU + 45 SALU per slot of 64-bit index arithmetic
+        // and exec-mask branches (tools/asm_mix.py: 2330 VALU per tile and wave against 540 for the residual epilogue).
         const int Da = QKV ? p.qkv_heads * p.qkv_head_dim : 1;
         const int part = QKV ? n / Da : 0;
         const int nn = QKV ? n - part * Da : 0;
         const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
+        const bool rot_lane = QKV && nok && part < 2;
+        const float q_mult = (QKV && part == 0) ? p.qkv_q_scale : 1.0f;
+        const bool any_rot = QKV && __any(rot_lane);                        // wave-uniform: a v-only strip skips the rotation
+        const int TS = QKV ? p.qkv_heads * p.qkv_tokens_pad * p.qkv_head_dim : 0;        // elements per image tile (< 2^31)
+        bf16_t* const qkv_P0 = QKV ? (bf16_t*)(part == 0 ? p.qkv_q : (part == 1 ? p.qkv_k : p.qkv_v)) +
+                                         ((int64_t)tile_w * p.qkv_heads + qh) * p.qkv_tokens_pad * p.qkv_head_dim + qd
+                                   : nullptr;
+        const float* const sc_P0 = QKV ? p.qkv_sin + (rot_lane ? qd : 0) : nullptr;
         auto sc_load = [&](int i, int t, int half) -> u32x4 {
             const int m = min(row_of(i, t), p.M - 1);
             int tile, tok;
             split_row(m, tile, tok);
             const int rt = max(tok - p.qkv_prefix, 0);
-            return *reinterpret_cast<const u32x4*>(p.qkv_sin + ((int64_t)rt * p.qkv_head_dim + (nok && part < 2 ? qd : 0)) + half * 4);
+            return *reinterpret_cast<const u32x4*>(sc_P0 + rt * p.qkv_head_dim + half * 4);
         };
         u32x4 sc[2][2][2];
         if (QKV) {
@@ -625,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int m = row_of(i, t);
-                    if (nok && m < p.M) *reinterpret_cast<u32x4*>((bf16_t*)p.C + dst_off(m)) = v2[t];
+                    if (nok && m < p.M) *reinterpret_cast<u32x4*>(dst_ptr(i, t, m)) = v2[t];
                 }
             } else {
 #pragma unroll
@@ -670,31 +708,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         if (QKV) {
                             int tile, tok;
                             split_row(m, tile, tok);
-                            if (part < 2) {
-                                if (tok >= p.qkv_prefix) {      // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs
+                            if (any_rot) {          // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs; q also carries its scale
+                                const bool rot = rot_lane && tok >= p.qkv_prefix;
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const u32x4 w = sc[i & 1][t][e >> 1];
-                                        const float sn = __uint_as_float(w[(e & 1) * 2]), cs = __uint_as_float(w[(e & 1) * 2 + 1]);
-                                        const float x0 = o[2 * e], x1 = o[2 * e + 1];
-                                        o[2 * e] = x0 * cs + (-x1) * sn;
-                                        o[2 * e + 1] = x1 * cs + x0 * sn;
-                                    }
+                                for (int e = 0; e < 4; ++e) {
+                                    const u32x4 w = sc[i & 1][t][e >> 1];
+                                    const float sn = (rot ? __uint_as_float(w[(e & 1) * 2]) : 0.0f) * q_mult;
+                                    const float cs = (rot ? __uint_as_float(w[(e & 1) * 2 + 1]) : 1.0f) * q_mult;
+                                    const float x0 = o[2 * e], x1 = o[2 * e + 1];
+                                    o[2 * e] = x0 * cs + (-x1) * sn;
+                                    o[2 * e + 1] = x1 * cs + x0 * sn;
                                 }
-                                if (part == 0) {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) o[e] *= p.qkv_q_scale;
-                                }
-                                st8((bf16_t*)(part == 0 ? p.qkv_q : p.qkv_k) +
-                                        (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
-                            } else if (p.qkv_v) {
-                                st8((bf16_t*)p.qkv_v +
-                                        (((int64_t)tile * p.qkv_heads + qh) * p.qkv_tokens_pad + tok) * p.qkv_head_dim + qd, o);
-                            } else {
-                                st8((bf16_t*)p.C + (int64_t)m * p.ldc + nn, o);
                             }
+                            st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
                         } else {
-                            st8((bf16_t*)p.C + dst_off(m), o);
+                            st8(dst_ptr(i, t, m), o);
                         }
                     }
                 }
@@ -876,7 +904,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
         constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
-        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || p.qkv_cos == nullptr)) {
+        if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || (p.qkv_cos == nullptr && p.qkv_v != nullptr))) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
         } else {
             if (wm == 0) __builtin_amdgcn_s_barrier();

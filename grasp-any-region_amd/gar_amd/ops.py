@@ -213,7 +213,8 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     p.bias = ptr(bias)
     # compact=False forces the general form (independent sin / cos tables, workgroup-level epilogue) that tables without the
     # pair structure take anyway
-    sc = _compact_sincos(sin, cos) if compact else None
+    # (the compact table goes with the per-wave epilogue, which writes v head-major: without V= the general form runs)
+    sc = _compact_sincos(sin, cos) if (compact and V is not None) else None
     if sc is not None:         # (sin, cos) pairs [tokens, hd/2, 2]: half the table bytes, the barrier-free per-wave epilogue
         p.qkv_q, p.qkv_k, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(K), ptr(sc), None
     else:

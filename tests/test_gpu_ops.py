@@ -993,6 +993,14 @@ def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact
     V2 = torch.zeros(T, H, Npad, hd, dtype=dt, device=dev)
     vrow2 = torch.full((T * N, D), 3.0, dtype=dt, device=dev)
     assert ops.gemm_qkv_rope(a, w, b, vrow2, Q2, K2, sin, cos, H, hd, N, Npad, npt, qs, compact=compact, V=V2)
-    assert torch.equal(Q2, Q1) and torch.equal(K2, K1)
+    if compact:
+        # the compact table goes with the branch-free per-wave epilogue (only with V=): the q scale is folded into
+        # (sin, cos) before the rotation there, after it in the general epilogue Q1 came from — fp32 rounding order only
+        close(Q2[:, :, :N], qref, dt)
+        close(K2[:, :, :N], kref, dt)
+        close(Q2, Q1.double().cpu(), dt)
+        close(K2, K1.double().cpu(), dt)
+    else:
+        assert torch.equal(Q2, Q1) and torch.equal(K2, K1)
     assert torch.equal(V2[:, :, :N], V1.transpose(2, 3)[:, :, :N])
     assert float((vrow2 - 3.0).abs().max()) == 0 and (Npad == N or float(V2[:, :, N:].abs().max()) == 0)
