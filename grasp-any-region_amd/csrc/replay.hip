@@ -81,6 +81,44 @@ extern "C" int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int6
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The reference's input checks of generate() evaluated on the device (GARModel.generate(validate=False) skips the host
+// syncs, not the checks): image-token count != feature rows (modeling_perception_lm.py:309-315), a crop-token span that
+// is not P*P long (the splice of modeling_gar.py:404-411 would change the sequence length), a crop token present in
+// input_ids without a bbox (modeling_gar.py:366: KeyError), ids outside [0, vocab). ORs GAR_INPUT_* bits into flags[0].
+// One block per sample; has_box[b] = bit c set iff sample b carries a bbox for crop token c.
+__global__ __launch_bounds__(256) void input_check_kernel(const int64_t* __restrict__ ids, int S, int64_t vocab,
+                                                          const int32_t* __restrict__ counts, int n_rows,
+                                                          const int32_t* __restrict__ spans, int n_crop, int span_len,
+                                                          const int32_t* __restrict__ has_box, int32_t* __restrict__ flags) {
+    const int b = blockIdx.x;
+    int bad = 0;
+    const int64_t* row = ids + (int64_t)b * S;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int64_t v = row[s];
+        if (v < 0 || v >= vocab) bad |= 8;
+    }
+    if (threadIdx.x == 0 && counts[b] != n_rows) bad |= 1;
+    if ((int)threadIdx.x < n_crop) {
+        const int lo = spans[((int64_t)b * n_crop + threadIdx.x) * 2], hi = spans[((int64_t)b * n_crop + threadIdx.x) * 2 + 1];
+        const bool present = hi >= 0, box = (has_box[b] >> threadIdx.x) & 1;
+        if (present && box && hi - lo + 1 != span_len) bad |= 2;
+        if (present && !box) bad |= 4;
+    }
+    if (__any(bad != 0) && bad) atomicOr(flags, bad);
+}
+
+extern "C" int gar_input_check(const int64_t* input_ids, int B, int S, int64_t vocab, const int32_t* counts, int n_rows,
+                               const int32_t* spans, int n_crop, int span_len, const int32_t* has_box, int32_t* flags,
+                               gar_stream_t stream) {
+    GAR_CHECK_ARG(input_ids && counts && spans && has_box && flags && B > 0 && S > 0 && n_crop >= 0 && n_crop <= 8,
+                  "input_check: bad args");
+    hipLaunchKernelGGL(input_check_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, input_ids, S, vocab, counts, n_rows,
+                       spans, n_crop, span_len, has_box, flags);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void embed_assemble_kernel(const int64_t* __restrict__ ids,
                                                              const int32_t* __restrict__ slot, const T* __restrict__ E,

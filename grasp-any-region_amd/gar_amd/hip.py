@@ -69,6 +69,7 @@ SIGNATURES = {
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),
     "gar_counter_add": ([_vp, _i, _i, _vp], _i),
+    "gar_input_check": ([_vp, _i, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp], _i),
 }
 
 _lib = None

@@ -523,19 +523,15 @@ class GARModel:
         else:
             ops.embed_assemble(ids, slot, self.E, feats, embeds, n_rows)
         if not validate:
-            # the same conditions, evaluated on the device and OR-ed into a flag nobody has to wait for:
-            # what the kernels do with such inputs (clamped slots / ids, P*P rows written from the span head) is defined
-            # but not what the reference computes
-            V = self.E.shape[0]
-            present = spans[..., 1] >= 0
-            has_box = torch.tensor([[str(t) in bboxes[b] for t in crop_ids] for b in range(B)], device=self.device)
-            bad = ((counts != n_rows).any().to(torch.int32) * INPUT_COUNT_MISMATCH
-                   | (present & has_box & (spans[..., 1] - spans[..., 0] + 1 != P * P)).any().to(torch.int32) * INPUT_SPAN_LENGTH
-                   | (present & ~has_box).any().to(torch.int32) * INPUT_MISSING_BBOX
-                   | ((ids < 0) | (ids >= V)).any().to(torch.int32) * INPUT_ID_RANGE)
+            # the same conditions, evaluated on the device by ONE small kernel and OR-ed into a flag nobody has to wait for
+            # (ADVICE r1 #5 / r2): what the kernels do with such inputs (clamped slots / ids, P*P rows written from the span
+            # head) is defined but not what the reference computes. The per-sample "has a bbox for crop token c" bits are the
+            # only host data (B int32, one small pinned upload).
+            hb = torch.tensor([sum(1 << ci for ci, t in enumerate(crop_ids) if str(t) in bboxes[b]) for b in range(B)],
+                              dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
             if getattr(self, "_input_flags", None) is None:
                 self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._input_flags |= bad
+            ops.input_check(ids, self.E.shape[0], counts, n_rows, spans, P * P, hb, self._input_flags)
         if validate:
             # reference errors (modeling_perception_lm.py:309-315, modeling_gar.py:356-360) need the counts on the host
             cnt = counts.tolist()

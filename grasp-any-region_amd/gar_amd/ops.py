@@ -384,5 +384,12 @@ def argmax_workspace(B, V) -> int:
     return int(lib().gar_argmax_workspace(B, V))
 
 
+def input_check(input_ids, vocab: int, counts, n_rows: int, spans, span_len: int, has_box, flags):
+    """device-side input checks of generate(validate=False): ORs INPUT_* bits into ``flags`` (int32 [1])."""
+    B, S = input_ids.shape
+    check(lib().gar_input_check(ptr(input_ids), B, S, int(vocab), ptr(counts), int(n_rows), ptr(spans), spans.shape[1],
+                                int(span_len), ptr(has_box), ptr(flags), stream()), "gar_input_check")
+
+
 def counter_add(counters, delta: int):
     check(lib().gar_counter_add(ptr(counters), counters.numel(), delta, stream()), "gar_counter_add")

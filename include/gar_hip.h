@@ -289,6 +289,15 @@ int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t*
 int64_t gar_argmax_workspace(int B, int V);
 int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 
+/* The input checks of the reference's generate() without a host sync: image-token count vs feature rows (ValueError,
+ * modeling_perception_lm.py:309-315), crop-token span length vs P*P (the splice of modeling_gar.py:404-411 would change
+ * the sequence length), crop token present but no bbox (KeyError, modeling_gar.py:366), ids outside [0, vocab).
+ * counts / spans: outputs of gar_placeholder_scan; has_box[b]: bit c set iff sample b has a bbox for crop token c.
+ * ORs bits 1 / 2 / 4 / 8 into flags[0] (device int32, not cleared here). */
+int gar_input_check(const int64_t* input_ids, int B, int S, int64_t vocab, const int32_t* counts, int n_rows,
+                    const int32_t* spans, int n_crop, int span_len, const int32_t* has_box, int32_t* flags,
+                    gar_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
