@@ -299,6 +299,12 @@ static int pick_waves(int n_blocks, int ksteps) {
 
 template <int EPI>
 static int launch(int dtype, const gar_gemm_params& p, hipStream_t s) {
+    if (p.row_scale || p.row_stats) {       // folded norms live in the bf16 tile GEMM's epilogues only
+        if (dtype == GAR_BF16 && p.split_k <= 1 && !p.norm_w && gar_gemm_pp_try(p, s)) return GAR_OK;
+        gar_set_error("gar_gemm: row_scale / row_stats are built for the bf16 tile GEMM (>= 128 tiles of 256 x 256) and the "
+                      "epilogues include/gar_hip.h lists (M=%d N=%d epilogue=%d)", p.M, p.N, p.epilogue);
+        return GAR_ERR_UNSUPPORTED;
+    }
     if (dtype == GAR_BF16 && p.M <= 64 && gar_skinny_bf16_try(p, s)) return GAR_OK;   // gemm_skinny.hip
     if (dtype == GAR_F32 && p.M <= 16) {
         constexpr int NT = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;

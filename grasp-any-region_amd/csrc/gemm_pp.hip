@@ -30,6 +30,7 @@
 //     256 x 256 tile whatever the stores hit (HBM or one L2-resident tile), ~15k with hardware bf16 rounding; the per-wave
 //     epilogue is worth another 2-11 % per GEMM on top.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "gemm_epilogue.h"
 
@@ -91,8 +92,7 @@ __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsi
 // Only the interval INDEX is clamped, not the interpolation weight: beyond the table the last / first interval is
 // extended linearly — gelu(x) = x to fp32 precision for x >= 8 (the last interval's slope is 1) and 0 for x <= -8 (the
 // first entry's slope is stored as 0) — so there is no range test: 7 VALU + one ds_read_b64 per element (9 with one).
-__device__ __forceinline__ float gelu_lut(float x, const char* lut) {
-    const float u = __builtin_fmaf(x, 128.0f, 1024.0f);
+__device__ __forceinline__ float gelu_lut_u(float u, const char* lut) {          // u = 128 x + 1024: the table coordinate
     const float fi = __builtin_floorf(__builtin_amdgcn_fmed3f(u, 0.0f, 2047.0f));
     const float2 e = *reinterpret_cast<const float2*>(lut + ((int)fi << 3));
     // one v_fma_f32 per element, pinned: left to itself the compiler pairs two elements into a v_pk_fma_f32 and pays three
@@ -100,6 +100,9 @@ __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
     float r;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(u - fi), "v"(e.x));
     return r;
+}
+__device__ __forceinline__ float gelu_lut(float x, const char* lut) {
+    return gelu_lut_u(__builtin_fmaf(x, 128.0f, 1024.0f), lut);
 }
 
 // Patch gather (GATHER, GAR_EPI_PATCH_POS only — gar_patch_embed): the A operand is not a matrix in HBM but the image
@@ -202,6 +205,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     // fetched one tile ahead. fp32 sum order changes from (products) + b to b + (products): one rounding of the bf16 result.
     constexpr bool BIAS_INIT = EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU || EPI == GAR_EPI_BIAS_SCALE_RES ||
                                EPI == GAR_EPI_QKV_ROPE;
+    // epilogues that can consume a folded norm (row_scale) / produce the statistics of one (row_stats)
+    constexpr bool RS_EPI = !GATHER && (EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU ||
+                                        EPI == GAR_EPI_SWIGLU || EPI == GAR_EPI_QKV_ROPE);
+    constexpr bool STATS_EPI = EPI == GAR_EPI_RES || EPI == GAR_EPI_BIAS_SCALE_RES;
+    const bool RS = RS_EPI && p.row_scale != nullptr;                      // uniform over the launch
     u32x4 bias_cur[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     auto load_bias = [&](int n0_, u32x4 (&b)[2]) {
 #pragma unroll
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float stat_s1[2] = {0.f, 0.f}, stat_s2[2] = {0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int m = row_of(i, t);
@@ -721,9 +730,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                 }
                             }
                             st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
+                        } else if (STATS_EPI && p.row_stats) {
+                            // folded norm, producer side: (sum, sum of squares) of this row's 64 ROUNDED outputs — 8 per lane,
+                            // the 8 lanes of the row by DPP (quad_perm xor 1, xor 2, row_half_mirror) — one float2 per row and strip
+                            const u32x4 pk = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
+                                s1 += lo + hi;
+                                s2 = __builtin_fmaf(lo, lo, s2);
+                                s2 = __builtin_fmaf(hi, hi, s2);
+                            }
+                            *reinterpret_cast<u32x4*>(dst_ptr(i, t, m)) = pk;
+                            stat_s1[t] = s1;
+                            stat_s2[t] = s2;
                         } else {
                             st8(dst_ptr(i, t, m), o);
                         }
+                    }
+                }
+                if (STATS_EPI && p.row_stats) {        // all lanes here: columns past N and rows past M contributed 0
+                    auto dpp_add = [](float v, auto ctrl) {
+                        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                                         0xf, 0xf, true));
+                    };
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float s1 = stat_s1[t], s2 = stat_s2[t];
+                        s1 = dpp_add(s1, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]: lane ^ 1
+                        s2 = dpp_add(s2, std::integral_constant<int, 0xB1>{});
+                        s1 = dpp_add(s1, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]: lane ^ 2
+                        s2 = dpp_add(s2, std::integral_constant<int, 0x4E>{});
+                        s1 = dpp_add(s1, std::integral_constant<int, 0x141>{});      // row_half_mirror: the other quad of the 8 lanes
+                        s2 = dpp_add(s2, std::integral_constant<int, 0x141>{});
+                        const int m = row_of(i, t);
+                        if (ch == 0 && m < p.M && n0 + wn * 64 < p.N)
+                            reinterpret_cast<float2*>(p.row_stats)[(int64_t)m * ((p.N + 63) >> 6) + ((n0 >> 6) + wn)] = make_float2(s1, s2);
                     }
                 }
             }
@@ -742,7 +785,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             m0n = tmn * PBM;
             n0n = tnn * PBM;
         }
-        if (BIAS_INIT) {
+        // Folded norm, consumer side (gar_gemm_params.row_scale): the accumulator rows are multiplied by rstd[m] before the
+        // epilogue and the bias is added AFTER that scale — so the chains start from 0 and bias_cur holds THIS tile's bias.
+        float rs[8];
+        if (RS_EPI && RS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rs[i] = p.row_scale[min(m0 + wm * 128 + i * 16 + frow, p.M - 1)];
+        }
+        if (BIAS_INIT && RS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            load_bias(n0, bias_cur);
+        } else if (BIAS_INIT) {
             // acc[i][j][r] is column 32 (j >> 1) + 8 fq + 4 (j & 1) + r of the wave's strip: element 4 (j & 1) + r of bias_cur[j >> 1]
             float bv[4][4];
 #pragma unroll
@@ -903,6 +959,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const unsigned tl_e0 = (unsigned)__builtin_amdgcn_s_memtime();
         tl_sum[12] += tl_e0 - tl[15];       // (the last K tile's barrier-7 release to here: ~0, keeps tl[15] live)
 #endif
+        if (RS_EPI && RS) {
+            // acc <- rstd[m] * acc + bias: the state every epilogue below expects at its entry (the bias in the accumulators)
+            float bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned w = bias_cur[j >> 1][((j & 1) * 4 + r) >> 1];
+                    bv[j][r] = !BIAS_INIT ? 0.f : ((r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16));
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = __builtin_fmaf(acc[i][j][r], rs[i], bv[j][r]);
+        }
         constexpr bool WAVE_EPI = EPI != GAR_EPI_SWIGLU;
         if (PERM && LDS_EPI && WAVE_EPI && !PP_DIAG_NOSTORE && (EPI != GAR_EPI_QKV_ROPE || (p.qkv_cos == nullptr && p.qkv_v != nullptr))) {
             epilogue_wave(smem + (sidx ^ 1) * PSTAGE);      // starts at once in each wave row; un-staggers inside
@@ -1021,6 +1094,12 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
     if (((int64_t)(p.M - 1) * p.lda + p.K) * 2 >= ((int64_t)1 << 32) - 4096 ||
         ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 >= ((int64_t)1 << 32) - 4096)
         return false;
+    // folded norms: row_scale on the consumer epilogues, row_stats on the producers (include/gar_hip.h)
+    const int e_ = p.epilogue;
+    if (p.row_scale && !(e_ == GAR_EPI_NONE || e_ == GAR_EPI_BIAS || e_ == GAR_EPI_BIAS_GELU || e_ == GAR_EPI_SWIGLU ||
+                         (e_ == GAR_EPI_QKV_ROPE && !p.qkv_cos && p.qkv_v)))
+        return false;
+    if (p.row_stats && !(e_ == GAR_EPI_RES || e_ == GAR_EPI_BIAS_SCALE_RES)) return false;
     switch (p.epilogue) {
         case GAR_EPI_NONE: launch_pp<GAR_EPI_NONE>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_BIAS: launch_pp<GAR_EPI_BIAS>(p, pm, pn, num_cus, s); break;

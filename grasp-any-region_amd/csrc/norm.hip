@@ -354,3 +354,85 @@ extern "C" int gar_rmsnorm(int dtype, const void* x, void* y, const void* w, int
                            float eps, gar_stream_t stream) {
     return launch_norm<true>(dtype, x, y, w, nullptr, M, D, ldx, ldy, eps, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Statistics half of a norm folded into the GEMM pair around it (gar_gemm_params.row_scale / row_stats, ABI v8).
+// row_rstd_kernel: one wave per row straight from x (two-pass variance like norm_kernel) — the first norm of a chain.
+// row_stats_finalize_kernel: one thread per row over the producer GEMM's (sum, sum of squares) partials, summed in
+// strip order (deterministic, independent of how the rows were tiled).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, bool RMS>
+__global__ __launch_bounds__(256) void row_rstd_kernel(const T* __restrict__ x, int M, int D, int64_t ldx, float eps,
+                                                       float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + (int64_t)row * ldx;
+    float s = 0.f;
+    for (int i = lane * 8; i < D; i += 512) {
+        float t[8];
+        ld8(xr + i, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = RMS ? __fmaf_rn(t[e], t[e], s) : s + t[e];
+    }
+    s = wave_sum(s);
+    float r;
+    if (RMS) {
+        r = rsqrtf(s / (float)D + eps);
+    } else {
+        const float mean = s / (float)D;
+        float q = 0.f;
+        for (int i = lane * 8; i < D; i += 512) {
+            float t[8];
+            ld8(xr + i, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = t[e] - mean; q = __fmaf_rn(d, d, q); }
+        }
+        q = wave_sum(q);
+        r = rsqrtf(q / (float)D + eps);
+    }
+    if (lane == 0) rstd[row] = r;
+}
+
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __restrict__ stats, int M, int strips, int D,
+                                                                 float eps, int rms, float* __restrict__ rstd) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float2* p = reinterpret_cast<const float2*>(stats) + (int64_t)row * strips;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < strips; ++k) {
+        const float2 v = p[k];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float inv = 1.0f / (float)D;
+    float var = s2 * inv;
+    if (!rms) {
+        const float mean = s1 * inv;
+        var = fmaxf(var - mean * mean, 0.f);
+    }
+    rstd[row] = rsqrtf(var + eps);
+}
+
+extern "C" int gar_row_rstd(int dtype, const void* x, int M, int D, int64_t ldx, float eps, int rms, float* rstd,
+                            gar_stream_t stream) {
+    GAR_CHECK_ARG(x && rstd && M > 0 && D > 0 && D % 8 == 0 && ldx >= D, "row_rstd: bad args");
+    GAR_CHECK_ARG(dtype == GAR_BF16 || dtype == GAR_F32, "row_rstd: bad dtype");
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_RR(TT, R_) hipLaunchKernelGGL((row_rstd_kernel<TT, R_>), grid, block, 0, s, (const TT*)x, M, D, ldx, eps, rstd)
+    if (dtype == GAR_BF16) { if (rms) LAUNCH_RR(bf16_t, true); else LAUNCH_RR(bf16_t, false); }
+    else { if (rms) LAUNCH_RR(float, true); else LAUNCH_RR(float, false); }
+#undef LAUNCH_RR
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+extern "C" int gar_row_stats_finalize(const float* row_stats, int M, int strips, int D, float eps, int rms, float* rstd,
+                                      gar_stream_t stream) {
+    GAR_CHECK_ARG(row_stats && rstd && M > 0 && strips > 0 && D > 0, "row_stats_finalize: bad args");
+    hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, row_stats, M,
+                       strips, D, eps, rms, rstd);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}

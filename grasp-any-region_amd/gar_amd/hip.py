@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
 GAR_F32, GAR_BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GarError(RuntimeError):
@@ -30,7 +30,8 @@ class GemmParams(C.Structure):
                 ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_sin", C.c_void_p), ("qkv_cos", C.c_void_p),
                 ("qkv_heads", C.c_int32), ("qkv_head_dim", C.c_int32), ("qkv_tokens", C.c_int32),
                 ("qkv_tokens_pad", C.c_int32), ("qkv_prefix", C.c_int32), ("qkv_q_scale", C.c_float),
-                ("split_k", C.c_int32), ("partial", C.c_void_p), ("qkv_v", C.c_void_p)]
+                ("split_k", C.c_int32), ("partial", C.c_void_p), ("qkv_v", C.c_void_p),
+                ("row_scale", C.c_void_p), ("row_stats", C.c_void_p)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -46,6 +47,8 @@ SIGNATURES = {
     "gar_cls_pos_fill": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "gar_layernorm": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
     "gar_rmsnorm": ([_i, _vp, _vp, _vp, _i, _i, _i64, _i64, _f, _vp], _i),
+    "gar_row_rstd": ([_i, _vp, _i, _i, _i64, _f, _i, _vp, _vp], _i),
+    "gar_row_stats_finalize": ([_vp, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "gar_splitk_residual_rmsnorm": ([_i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "gar_vit_v_transpose": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),

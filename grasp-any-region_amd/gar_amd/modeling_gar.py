@@ -164,6 +164,11 @@ class _MllmFacade:
 
 
 class GARModel:
+    # bf16: the LayerNorms of the ViT blocks and the RMSNorms of the Llama prefill are folded into the GEMM pairs around
+    # them (gar_gemm_params.row_scale / row_stats): the consumer GEMM reads the residual stream itself with a weight that
+    # carries gamma (and, for LayerNorm, centred rows), the producer GEMM's epilogue writes the row statistics — the
+    # stand-alone norm passes (3.3 % of a step, at HBM bandwidth) disappear
+    FOLD_NORMS = True
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
@@ -302,15 +307,29 @@ class GARModel:
             out[:, :, :hd] = w.reshape(w.shape[0], H, hd)
             return out.reshape(w.shape[0], H * hdp)
 
+        fold = self.dtype == torch.bfloat16
+
+        def fold_ln(w, bias, gamma, beta):
+            """LN(x) W^T + b = rstd * (x Wc^T) + b': Wc = W diag(gamma) with every row's mean removed (the mean subtraction
+            of the LayerNorm is linear and is absorbed by the weight), b' = b + W beta. fp32 in, model dtype out."""
+            wg = w.float() * gamma.float()[None, :]
+            return d(wg - wg.mean(dim=1, keepdim=True)), d(bias.float() + w.float() @ beta.float())
+
         for i in range(v.depth):
             b = f"{VT}blocks.{i}."
-            self.vblocks.append(dict(
+            extra = {}
+            if fold:
+                qw, qb = pad_qkv(W[b + "attn.qkv.weight"]), pad_qkv(W[b + "attn.qkv.bias"])
+                extra["qkv_wf"], extra["qkv_bf"] = fold_ln(qw, qb, W[b + "norm1.weight"], W[b + "norm1.bias"])
+                extra["fc1_wf"], extra["fc1_bf"] = fold_ln(W[b + "mlp.fc1.weight"], W[b + "mlp.fc1.bias"],
+                                                           W[b + "norm2.weight"], W[b + "norm2.bias"])
+            self.vblocks.append(dict(**extra, **dict(
                 n1=(d(W[b + "norm1.weight"]), d(W[b + "norm1.bias"])),
                 qkv_w=d(pad_qkv(W[b + "attn.qkv.weight"])), qkv_b=d(pad_qkv(W[b + "attn.qkv.bias"])),
                 proj_w=d(pad_proj(W[b + "attn.proj.weight"])), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
                 n2=(d(W[b + "norm2.weight"]), d(W[b + "norm2.bias"])),
                 fc1_w=d(W[b + "mlp.fc1.weight"]), fc1_b=d(W[b + "mlp.fc1.bias"]),
-                fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"])))
+                fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"]))))
         self.pj = dict(w1=d(W[PJ + "linear_1.weight"]), b1=d(W[PJ + "linear_1.bias"]),
                        w2=d(W[PJ + "linear_2.weight"]), b2=d(W[PJ + "linear_2.bias"]))
         sin, cos = _rope2d_tables(v)
@@ -330,7 +349,11 @@ class GARModel:
             g, u = W[b + "mlp.gate_proj.weight"], W[b + "mlp.up_proj.weight"]
             # [gate16 | up16] row interleave expected by GAR_EPI_SWIGLU
             gu = torch.stack([g.view(F // 16, 16, -1), u.view(F // 16, 16, -1)], dim=1).reshape(2 * F, -1)
-            self.layers.append(dict(ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv),
+            extra = {}
+            if fold:          # RMSNorm folded: W diag(g) (prefill only; the decode GEMVs keep the plain weights)
+                extra["qkv_f"] = d(qkv.float() * W[b + "input_layernorm.weight"].float()[None, :])
+                extra["gu_f"] = d(gu.float() * W[b + "post_attention_layernorm.weight"].float()[None, :])
+            self.layers.append(dict(**extra, ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv),
                                     o=d(W[b + "self_attn.o_proj.weight"]),
                                     ln2=d(W[b + "post_attention_layernorm.weight"]), gu=d(gu),
                                     down=d(W[b + "mlp.down_proj.weight"])))
@@ -405,7 +428,6 @@ class GARModel:
         Npad = _round_up(N, 64)
         key = ("vit", Tt)
         x = self._buf(key, "x", (Tt, N, D))
-        hbuf = self._buf(key, "h", (Tt * N, D))
         # zero-initialised once: the fused qkv GEMM writes the N real token rows only, rows N..Npad must stay finite
         Q = self._buf(key, "Q", (Tt, H, Npad, hd), zero=True)
         K = self._buf(key, "K", (Tt, H, Npad, hd), zero=True)
@@ -436,7 +458,33 @@ class GARModel:
             ops.cls_pos_fill(x, self.cls, self.pos)
         ops.layernorm(x2, *self.norm_pre, v.ln_eps)
         q_scale = (v.head_dim ** -0.5) * LOG2E
-        for blk in self.vblocks:
+        f1v = f1.view(-1)[:Tt * N * Dm].view(Tt * N, Dm)
+        # Folded LayerNorms (bf16, passes large enough for the tile GEMM): qkv and fc1 read the residual stream x itself with
+        # the folded weights and scale their accumulator rows by rstd; proj and fc2 write x's row statistics from their
+        # epilogues; a one-thread-per-row kernel turns them into rstd. No LayerNorm pass, no normalised copy of x.
+        fold = (self.FOLD_NORMS and fused and Vr is not None and "qkv_wf" in self.vblocks[0] and
+                ops.tile_gemm_takes(Tt * N, D) and D % 64 == 0)
+        if fold:
+            rstd = self._buf(key, "rstd", (Tt * N,), torch.float32)
+            stats = self._buf(key, "stats", (Tt * N, D // 64, 2), torch.float32)
+            ops.row_rstd(x2, v.ln_eps, False, rstd)                  # LN1 of block 0: its input came out of norm_pre
+            for bi, blk in enumerate(self.vblocks):
+                if not ops.gemm_qkv_rope(x2, blk["qkv_wf"], blk["qkv_bf"], att, Q, K, self.vit_sin, self.vit_cos, H, hd, N,
+                                         Npad, self.npt, q_scale, V=Vr, row_scale=rstd):
+                    raise hip.GarError("folded qkv GEMM refused a shape tile_gemm_takes() accepted")
+                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True,
+                              kv_prefix=self.npt if self.VIT_CLS_KEY_FOLD and N > 1 else 0)
+                ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"],
+                         row_stats=stats)
+                ops.row_stats_finalize(stats, D, v.ln_eps, False, rstd)
+                ops.gemm(x2, blk["fc1_wf"], f1v, hip.EPI_BIAS_GELU, bias=blk["fc1_bf"], row_scale=rstd)
+                last = bi + 1 == len(self.vblocks)
+                ops.gemm(f1v, blk["fc2_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["fc2_b"], residual=x2, gamma=blk["g2"],
+                         row_stats=None if last else stats)
+                if not last:
+                    ops.row_stats_finalize(stats, D, v.ln_eps, False, rstd)
+        hbuf = None if fold else self._buf(key, "h", (Tt * N, D))
+        for blk in ([] if fold else self.vblocks):
             ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
             if fused:
                 if Vr is None and vrow is None:
@@ -464,7 +512,6 @@ class GARModel:
                 ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
             ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])
             ops.layernorm(x2, *blk["n2"], v.ln_eps, out=hbuf)
-            f1v = f1.view(-1)[:Tt * N * Dm].view(Tt * N, Dm)
             ops.gemm(hbuf, blk["fc1_w"], f1v, hip.EPI_BIAS_GELU, bias=blk["fc1_b"])
             ops.gemm(f1v, blk["fc2_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["fc2_b"], residual=x2, gamma=blk["g2"])
         # projector over all N tokens of a tile (cls row included, dropped by the pooling window)
@@ -611,7 +658,7 @@ class GARModel:
         Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
         key = ("prefill", B, S)
         h = embeds.view(B * S, C_l)
-        xn = self._buf(key, "xn", (B * S, C_l))
+        xn = None                                      # the normalised copy of h: only without folded norms
         qkv = self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
         Spad = _round_up(S, 64)
         Q = self._buf(key, "Q", (B, Hq, Spad, hd))
@@ -620,16 +667,38 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         lp = st["left_pad"][b0:b0 + B]
+        # Folded RMSNorms (bf16, tile-GEMM sized passes): qkv and gate/up read the residual stream h with W diag(g) and scale
+        # their accumulator rows by rstd; o and down write h's row sums of squares from their epilogues (see get_image_features)
+        fold = (self.FOLD_NORMS and self.dtype == torch.bfloat16 and "qkv_f" in self.layers[0] and
+                ops.tile_gemm_takes(B * S, C_l) and C_l % 64 == 0)
+        if fold:
+            rstd = self._buf(key, "rstd", (B * S,), torch.float32)
+            stats = self._buf(key, "stats", (B * S, C_l // 64, 2), torch.float32)
+            ops.row_rstd(h, t.rms_norm_eps, True, rstd)                  # input_layernorm of layer 0: h came from the embedding pass
+        else:
+            xn = self._buf(key, "xn", (B * S, C_l))
         for li, ly in enumerate(self.layers):
             Kc, Vtc = st["Kc"][li][b0:b0 + B], st["Vtc"][li][b0:b0 + B]       # this chunk's rows of the shared cache
-            ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
-            ops.gemm(xn, ly["qkv"], qkv)
+            if fold:
+                ops.gemm(h, ly["qkv_f"], qkv, row_scale=rstd)
+            else:
+                ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["qkv"], qkv)
             ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale, left_pad=lp)
             ops.attention(Q, Kc, Vtc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp)
-            ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
-            ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
-            ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
-            ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
+            if fold:
+                ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h, row_stats=stats)
+                ops.row_stats_finalize(stats, C_l, t.rms_norm_eps, True, rstd)
+                ops.gemm(h, ly["gu_f"], ff, hip.EPI_SWIGLU, row_scale=rstd)
+                last = li + 1 == len(self.layers)
+                ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h, row_stats=None if last else stats)
+                if not last:
+                    ops.row_stats_finalize(stats, C_l, t.rms_norm_eps, True, rstd)
+            else:
+                ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
+                ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+                ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
 
     def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None):

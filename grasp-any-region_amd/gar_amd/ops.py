@@ -37,7 +37,8 @@ def _chk(t: torch.Tensor, name: str):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, bias=None, residual=None,
          gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0, norm_w=None,
-         norm_eps: float = 0.0, partial: Optional[torch.Tensor] = None):
+         norm_eps: float = 0.0, partial: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+         row_stats: Optional[torch.Tensor] = None):
     """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views.
     ``partial`` fp32 [split_k, M, N] (decode GEMMs, EPI_NONE): the K range is cut into split_k slices whose products go
     there instead of ``out`` (pass ``out=None``); ``splitk_residual_rmsnorm`` reduces them."""
@@ -64,6 +65,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     p.pos = ptr(pos)
     p.tokens_in, p.tokens_out, p.token_offset = tokens_in, tokens_out, token_offset
     p.norm_w, p.norm_eps = ptr(norm_w), norm_eps
+    # folded norm (include/gar_hip.h): row_scale [M] fp32 multiplies the accumulator rows; row_stats [M, ceil(N/64), 2] fp32
+    # receives (sum, sum of squares) of the rounded outputs per 64-column strip
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and row_scale.numel() >= M
+    if row_stats is not None:
+        assert row_stats.dtype == torch.float32 and row_stats.is_contiguous() and \
+            tuple(row_stats.shape) == (M, (N + 63) // 64, 2)
+    p.row_scale, p.row_stats = ptr(row_scale), ptr(row_stats)
     prof = KERNEL_TIMERS
     if prof is not None and not torch.cuda.is_current_stream_capturing():
         # HIP events on the launch stream around this one kernel (bench.py roofline; never inside graph capture)
@@ -76,6 +85,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         return out
     check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
     return out
+
+
+def tile_gemm_takes(M: int, N: int) -> bool:
+    """True when a bf16 [M, K] x [N, K]^T problem runs on the persistent 256 x 256 tile GEMM (csrc/gemm_pp.hip,
+    gar_gemm_pp_try) — the kernel whose epilogues carry the folded norms (row_scale / row_stats)."""
+    return N >= 256 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
 
 
 def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[torch.Tensor], eps: float,
@@ -175,6 +190,25 @@ def rmsnorm(x, w, eps: float, out=None):
     return out
 
 
+def row_rstd(x, eps: float, rms: bool, out):
+    """out[m] = rsqrt(var(x[m]) + eps) (LayerNorm) or rsqrt(mean(x[m]^2) + eps) (RMSNorm), fp32 [M]: the statistics half of a
+    norm whose scaling half is folded into the next GEMM (``gemm(..., row_scale=out)``)."""
+    M, D, ldx = _rows(x)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= M
+    check(lib().gar_row_rstd(dtype_code(x.dtype), ptr(x), M, D, ldx, eps, int(rms), ptr(out), stream()), "gar_row_rstd")
+    return out
+
+
+def row_stats_finalize(stats, D: int, eps: float, rms: bool, out):
+    """stats [M, strips, 2] fp32 (sum, sum of squares per 64-column strip, written by a producer GEMM's ``row_stats=``)
+    -> out[m] = rstd of row m."""
+    M, strips, two = stats.shape
+    assert two == 2 and stats.dtype == torch.float32 and stats.is_contiguous() and out.dtype == torch.float32
+    check(lib().gar_row_stats_finalize(ptr(stats), M, strips, D, eps, int(rms), ptr(out), stream()),
+          "gar_row_stats_finalize")
+    return out
+
+
 def vit_qkv_post(qkv, sin, cos, Q, K, Vt, T, N, npt, H, hd, Npad, q_scale):
     check(lib().gar_vit_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(sin), ptr(cos), ptr(Q), ptr(K), ptr(Vt), T, N, npt,
                                  H, hd, Npad, q_scale, stream()), "gar_vit_qkv_post")
@@ -198,7 +232,8 @@ def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
 
 
 def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_pad, prefix, q_scale,
-                  compact: bool = True, V: Optional[torch.Tensor] = None) -> bool:
+                  compact: bool = True, V: Optional[torch.Tensor] = None,
+                  row_scale: Optional[torch.Tensor] = None) -> bool:
     """qkv GEMM with the front half of timm AttentionRope fused (GAR_EPI_QKV_ROPE): q / k are rotated, scaled and written
     straight into Q / K [tiles, heads, tokens_pad, hd]; v goes row-major to ``v_out`` [M, heads*hd]. Returns False when the
     library does not take this shape / dtype on the fused path (caller keeps gemm + vit_qkv_post)."""
@@ -224,6 +259,7 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     # V [tiles, heads, tokens_pad, hd]: v leaves the GEMM head-major like k (attention(..., v_row_major=True) reads it in
     # place); v_out is then not written
     p.qkv_v = ptr(V)
+    p.row_scale = ptr(row_scale)           # folded LayerNorm: a = the residual stream itself, w / bias the folded pair
     prof = KERNEL_TIMERS
     timed = prof is not None and not torch.cuda.is_current_stream_capturing()
     if timed:

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 7
+#define GAR_ABI_VERSION 8
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -90,6 +90,15 @@ typedef struct gar_gemm_params {
     /* GAR_EPI_QKV_ROPE: when not NULL, v goes here head-major [tiles, heads, qkv_tokens_pad, head_dim] — the layout of
      * qkv_k, consumed by gar_attention_vrow — instead of row-major to C (which then is not written) */
     void* qkv_v;
+    /* A LayerNorm / RMSNorm folded into the GEMM pair around it (bf16 tile GEMM; ABI v8). The normalisation of the residual
+     * stream x is linear up to a per-row scale: LN(x) W^T + b = rstd_m * (x W''^T) + b' with W'' = (W diag(gamma)) minus each
+     * row's mean (the mean subtraction is absorbed by centring the weight rows), b' = b + W beta; RMSNorm: W'' = W diag(g).
+     *   row_scale [M] fp32: C = epilogue(row_scale[m] * (A W^T) + bias) — the CONSUMER (qkv / fc1 / gate-up GEMM reading x
+     *     itself; GAR_EPI_NONE, BIAS, BIAS_GELU, SWIGLU, QKV_ROPE with the compact table);
+     *   row_stats [M][ceil(N/64)][2] fp32: per row and 64-column strip (sum y, sum y^2) of the bf16-rounded outputs y — the
+     *     PRODUCER of x (GAR_EPI_RES, GAR_EPI_BIAS_SCALE_RES); gar_row_stats_finalize turns them into row_scale. */
+    const float* row_scale;
+    float* row_stats;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -130,6 +139,14 @@ int gar_cls_pos_fill(int dtype, void* x, const void* cls, const void* pos, int T
  * ldx / ldy = row strides in elements (<= 0 means D). */
 int gar_layernorm(int dtype, const void* x, void* y, const void* w, const void* b, int M, int D, int64_t ldx,
                   int64_t ldy, float eps, gar_stream_t stream);
+/* The statistics half of a norm whose scaling half is folded into the next GEMM (gar_gemm_params.row_scale):
+ * gar_row_rstd: rstd[m] = rsqrt(var(x[m, :]) + eps) (rms = 0; two-pass variance) or rsqrt(mean(x^2) + eps) (rms = 1) straight
+ *   from x — the first norm of a chain, whose input no GEMM epilogue produced;
+ * gar_row_stats_finalize: the same from the (sum, sum of squares) partials a producer GEMM wrote (row_stats, `strips`
+ *   pairs per row, summed in strip order: deterministic). timm LayerNorm / HF LlamaRMSNorm statistics, fp32. */
+int gar_row_rstd(int dtype, const void* x, int M, int D, int64_t ldx, float eps, int rms, float* rstd, gar_stream_t stream);
+int gar_row_stats_finalize(const float* row_stats, int M, int strips, int D, float eps, int rms, float* rstd,
+                           gar_stream_t stream);
 int gar_rmsnorm(int dtype, const void* x, void* y, const void* w, int M, int D, int64_t ldx, int64_t ldy, float eps,
                 gar_stream_t stream);
 /* The reduction of a split-K decode GEMM fused with what follows it in a Llama layer (HF LlamaDecoderLayer:

@@ -404,6 +404,46 @@ def test_bf16_gar8b_dims_one_layer():
     assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
 
 
+def test_bf16_folded_norms_gar1b_dims():
+    """The LayerNorms of the ViT blocks and the RMSNorms of the Llama prefill folded into the GEMMs around them
+    (GARModel.FOLD_NORMS: consumer GEMMs read the residual stream with gamma-carrying, row-centred weights and scale their
+    accumulator rows by rstd; producer GEMMs write the row statistics) against the same model with stand-alone norm passes
+    and against the f32 oracle on the bf16-rounded weights — GAR-1B dims, two ViT blocks and two Llama layers so that the
+    statistics of one block's proj / fc2 (o / down) feed the next block's qkv / fc1 (qkv / gate-up)."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b(**{"vision.depth": 2, "text.num_hidden_layers": 2})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16)
+    s = _sample(cfg, proc, 3, 1024, 1024, dtype=torch.bfloat16)
+    Wq = {k: v.to(torch.bfloat16).float() for k, v in W.items()}
+    ref_seq, ref_logits = _oracle(Wq, cfg, s, 1, attn_impl="sdpa")
+    m = GARModel(cfg, W, torch.bfloat16)
+    assert m.FOLD_NORMS and "qkv_wf" in m.vblocks[0] and "gu_f" in m.layers[0]
+    folded = m.generate(**s, max_new_tokens=4, return_logits=True)
+    assert "rstd" in m._ws[("vit",)] and "rstd" in m._ws[("prefill",)] and "h" not in m._ws[("vit",)]      # the folded path ran
+    feats_f = m.get_image_features(s["pixel_values"], s["global_mask_values"]).clone()
+    m.FOLD_NORMS = False
+    plain = m.generate(**s, max_new_tokens=4, return_logits=True)
+    feats_p = m.get_image_features(s["pixel_values"], s["global_mask_values"]).clone()
+    # both are bf16 evaluations of the same function with different rounding points
+    ef, ep = _rel_l2(folded.logits.cpu()[:, 0], ref_logits[:, 0]), _rel_l2(plain.logits.cpu()[:, 0], ref_logits[:, 0])
+    print(f"folded norms: features folded vs plain rel-L2 {_rel_l2(feats_f, feats_p):.3e}; first-token logits vs the f32 oracle: "
+          f"folded {ef:.3e}, plain {ep:.3e}; folded vs plain {_rel_l2(folded.logits[:, 0], plain.logits[:, 0]):.3e}")
+    assert _rel_l2(feats_f, feats_p) < 1.5e-2
+    assert ef < BF16_LOGIT_TOL and ep < BF16_LOGIT_TOL
+    assert _rel_l2(folded.logits[:, 0], plain.logits[:, 0]) < BF16_LOGIT_TOL          # two bf16 roundings of one function
+    # a row's result does not depend on its neighbours or on the pass it rides in: two identical samples, bit-identical rows
+    m.FOLD_NORMS = True
+    two = dict(input_ids=torch.cat([s["input_ids"]] * 2), pixel_values=torch.cat([s["pixel_values"]] * 2),
+               global_mask_values=torch.cat([s["global_mask_values"]] * 2), bboxes=s["bboxes"] * 2,
+               aspect_ratios=torch.cat([s["aspect_ratios"]] * 2))
+    o2 = m.generate(**two, max_new_tokens=2, return_logits=True)
+    assert torch.equal(o2.logits[0], o2.logits[1]) and torch.equal(o2.logits[0, 0], folded.logits[0, 0])
+
+
 def test_f32_parity_gar1b_dims_multi_region_one_layer():
     """BASELINE.json configs[2]: 4 masks per 1024^2 image, relationship prompt, GAR-1B shapes (one layer each):
     four 256-row RoI replays spliced into one ~5.5k-token sequence, f32 token parity with the oracle."""

@@ -929,6 +929,156 @@ def test_decode_gemm_split_k_and_fused_reduce(dev, M, S):
         ops.gemm(xg, wg, None, hip.EPI_RES, residual=h1, partial=partial)
 
 
+def _fold_ln(W, b, gamma, beta):
+    """LN(x) W^T + b = rstd * (x Wc^T) + b':  Wc = W diag(gamma) minus each row's mean,  b' = b + W beta"""
+    Wg = W.double() * gamma.double()[None, :]
+    return (Wg - Wg.mean(1, keepdim=True)).float(), (b.double() + W.double() @ beta.double()).float()
+
+
+def test_row_rstd_and_stats_finalize(dev):
+    from gar_amd import ops
+    M, D = 1000, 1024
+    x = q(rnd(M, D, seed=90) * 2.0 + 0.7, torch.bfloat16)
+    xd = x.to(dev, torch.bfloat16)
+    for rms in (False, True):
+        out = torch.empty(M, dtype=torch.float32, device=dev)
+        ops.row_rstd(xd, 1e-5, rms, out)
+        var = x.double().pow(2).mean(1) if rms else x.double().var(1, unbiased=False)
+        ref = (var + 1e-5).rsqrt()
+        assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        # the same from per-strip partials
+        st = torch.stack([x.double().view(M, 16, 64).sum(-1), x.double().view(M, 16, 64).pow(2).sum(-1)], -1).float()
+        out2 = torch.empty(M, dtype=torch.float32, device=dev)
+        ops.row_stats_finalize(st.to(dev).contiguous(), D, 1e-5, rms, out2)
+        assert float((out2.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "none_rms", "swiglu_rms"])
+def test_gemm_row_scale_is_the_folded_norm(dev, epi):
+    """gar_gemm_params.row_scale: the norm in front of a GEMM folded into it — x goes in un-normalised, the weight is
+    W diag(gamma) with centred rows (LayerNorm) or W diag(g) (RMSNorm), the accumulator rows are scaled by rstd[m] and the
+    folded bias is added after the scale. Against the fp64 norm -> linear (-> GELU / SwiGLU) of the same bf16 inputs."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    M, K, N = 8300, 1024, 1024
+    x = q(rnd(M, K, seed=91) * 1.5 + 0.4, dt)
+    W = rnd(N, K, seed=92, scale=K ** -0.5)
+    gamma, beta, b = 1.0 + 0.1 * rnd(K, seed=93), 0.1 * rnd(K, seed=94), 0.1 * rnd(N, seed=95)
+    xd = x.to(dev, dt)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    rms = epi.endswith("rms")
+    ops.row_rstd(xd, 1e-5, rms, rstd)
+    xs = x.double()
+    if rms:
+        Wf = q(W * gamma[None, :], dt)
+        normed = xs * (xs.pow(2).mean(1, keepdim=True) + 1e-5).rsqrt()
+        ref = normed @ Wf.double().T                    # gamma folded: compare against the folded (rounded) weight itself
+        bf = None
+    else:
+        Wc, bp = _fold_ln(W, b, gamma, beta)
+        Wf, bf = q(Wc, dt), q(bp, dt)
+        normed = (xs - xs.mean(1, keepdim=True)) * (xs.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        # what the fold computes exactly: rstd * (x Wf^T) + b'; and that it IS the LayerNorm -> linear (up to Wf's rounding)
+        ref = (xs @ Wf.double().T) * (xs.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() + bf.double()
+        ln_lin = (normed * gamma.double() + beta.double()) @ W.double().T + b.double()
+        assert float((ref - ln_lin).abs().max() / ln_lin.abs().max()) < 1e-2
+    if epi == "bias":
+        out = torch.empty(M, N, dtype=dt, device=dev)
+        ops.gemm(xd, Wf.to(dev, dt), out, hip.EPI_BIAS, bias=bf.to(dev, dt), row_scale=rstd)
+    elif epi == "gelu":
+        out = torch.empty(M, N, dtype=dt, device=dev)
+        ops.gemm(xd, Wf.to(dev, dt), out, hip.EPI_BIAS_GELU, bias=bf.to(dev, dt), row_scale=rstd)
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "none_rms":
+        out = torch.empty(M, N, dtype=dt, device=dev)
+        ops.gemm(xd, Wf.to(dev, dt), out, hip.EPI_NONE, row_scale=rstd)
+    else:
+        out = torch.empty(M, N // 2, dtype=dt, device=dev)
+        ops.gemm(xd, Wf.to(dev, dt), out, hip.EPI_SWIGLU, row_scale=rstd)
+        r = ref.view(M, N // 32, 2, 16)                  # [gate16 | up16] row blocks
+        ref = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, N // 2)
+    close(out, ref, dt, extra=1.5)
+    # small problems do not take the tile GEMM: refused, not silently unscaled
+    with pytest.raises(hip.GarError):
+        ops.gemm(xd[:64], Wf.to(dev, dt), torch.empty(64, N, dtype=dt, device=dev), hip.EPI_NONE, row_scale=rstd)
+
+
+@pytest.mark.parametrize("epi", ["res", "bsr"])
+def test_gemm_row_stats_of_the_rounded_outputs(dev, epi):
+    """gar_gemm_params.row_stats: the producer of a folded norm writes (sum, sum of squares) of its bf16-ROUNDED output rows
+    per 64-column strip; finalize gives the rstd a LayerNorm / RMSNorm of that output would compute. M and N tails."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    M, K, N = 8300, 256, 1000
+    a = q(rnd(M, K, seed=96), dt).to(dev, dt)
+    w = q(rnd(N, K, seed=97, scale=K ** -0.5), dt).to(dev, dt)
+    res = q(rnd(M, N, seed=98), dt).to(dev, dt)
+    out = torch.empty(M, N, dtype=dt, device=dev)
+    strips = (N + 63) // 64
+    st = torch.full((M, strips, 2), float("nan"), dtype=torch.float32, device=dev)
+    if epi == "res":
+        ops.gemm(a, w, out, hip.EPI_RES, residual=res, row_stats=st)
+        plain = torch.empty_like(out)
+        ops.gemm(a, w, plain, hip.EPI_RES, residual=res)
+    else:
+        bias, gam = q(rnd(N, seed=99), dt).to(dev, dt), q(0.1 + 0.01 * rnd(N, seed=100), dt).to(dev, dt)
+        ops.gemm(a, w, out, hip.EPI_BIAS_SCALE_RES, bias=bias, residual=res, gamma=gam, row_stats=st)
+        plain = torch.empty_like(out)
+        ops.gemm(a, w, plain, hip.EPI_BIAS_SCALE_RES, bias=bias, residual=res, gamma=gam)
+    assert torch.equal(out, plain)                                   # the statistics do not change the output
+    o = out.double().cpu()
+    pad = torch.zeros(M, strips * 64, dtype=torch.float64)
+    pad[:, :N] = o
+    ref = torch.stack([pad.view(M, strips, 64).sum(-1), pad.view(M, strips, 64).pow(2).sum(-1)], -1)
+    got = st.cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    for rms in (False, True):
+        r = torch.empty(M, dtype=torch.float32, device=dev)
+        ops.row_stats_finalize(st, N, 1e-5, rms, r)
+        var = o.pow(2).mean(1) if rms else o.var(1, unbiased=False)
+        want = (var + 1e-5).rsqrt()
+        assert float((r.cpu().double() - want).abs().max() / want.abs().max()) < 1e-4
+
+
+def test_fused_qkv_rope_with_folded_layernorm(dev):
+    """GAR_EPI_QKV_ROPE fed with the residual stream itself (row_scale = rstd, folded weight / bias): q, k, v equal the fp64
+    LayerNorm -> qkv linear -> interleaved RoPE (-> q scale) of the same bf16 x, in attention layout."""
+    from gar_amd import ops
+    dt = torch.bfloat16
+    T, n, npt, hd, H = 9, 1024, 1, 64, 16
+    N, D, Kd = n + npt, 16 * 64, 256
+    Npad = (N + 63) // 64 * 64
+    x = q(rnd(T * N, Kd, seed=110) * 1.3 + 0.2, dt)
+    W = rnd(3 * D, Kd, seed=111, scale=Kd ** -0.5)
+    gamma, beta, b = 1.0 + 0.1 * rnd(Kd, seed=112), 0.1 * rnd(Kd, seed=113), 0.2 * rnd(3 * D, seed=114)
+    Wc, bp = _fold_ln(W, b, gamma, beta)
+    Wf, bf = q(Wc, dt), q(bp, dt)
+    sin = torch.sin(rnd(n, hd // 2, seed=115)).repeat_interleave(2, -1).contiguous().to(dev)
+    cos = torch.cos(rnd(n, hd // 2, seed=115)).repeat_interleave(2, -1).contiguous().to(dev)
+    qs = hd ** -0.5 * 1.4426950408889634
+    xd = x.to(dev, dt)
+    rstd = torch.empty(T * N, dtype=torch.float32, device=dev)
+    ops.row_rstd(xd, 1e-5, False, rstd)
+    Q1, K1, V1 = (torch.zeros(T, H, Npad, hd, dtype=dt, device=dev) for _ in range(3))
+    dummy = torch.empty(T * N, D, dtype=dt, device=dev)
+    assert ops.gemm_qkv_rope(xd, Wf.to(dev, dt), bf.to(dev, dt), dummy, Q1, K1, sin, cos, H, hd, N, Npad, npt, qs, V=V1,
+                             row_scale=rstd)
+    xs = x.double()
+    full = ((xs @ Wf.double().T) * (xs.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() + bf.double()).view(T, N, 3, H, hd)
+    qr, kr, vr = full[:, :, 0], full[:, :, 1], full[:, :, 2]
+
+    def rope(t):
+        tr = t.clone()
+        body = t[:, npt:]
+        rot = torch.stack([-body[..., 1::2], body[..., 0::2]], -1).reshape(body.shape)
+        tr[:, npt:] = body * cos.cpu().double()[None, :, None, :] + rot * sin.cpu().double()[None, :, None, :]
+        return tr
+    close(Q1[:, :, :N], (rope(qr) * qs).permute(0, 2, 1, 3), dt, extra=1.5)
+    close(K1[:, :, :N], rope(kr).permute(0, 2, 1, 3), dt, extra=1.5)
+    close(V1[:, :, :N], vr.permute(0, 2, 1, 3), dt, extra=1.5)
+
+
 def test_abi_errors_are_reported_not_thrown(dev):
     from gar_amd import hip, ops
     a = torch.zeros(4, 60, device=dev)

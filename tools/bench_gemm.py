@@ -43,6 +43,13 @@ def main():
         No = N // 2 if epi == hip.EPI_SWIGLU else N
         out = torch.empty(M, No + pad_c, device=dev, dtype=torch.bfloat16)[:, :No]
         kw = {}
+        fold = os.environ.get("FOLD") == "1"          # folded norms: row_scale on the consumers, row_stats on the producers
+        rs = torch.rand(M, device=dev) + 0.5 if fold and epi in (hip.EPI_NONE, hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_SWIGLU,
+                                                                    hip.EPI_QKV_ROPE) else None
+        if fold and epi in (hip.EPI_RES, hip.EPI_BIAS_SCALE_RES):
+            kw["row_stats"] = torch.empty(M, (N + 63) // 64, 2, device=dev, dtype=torch.float32)
+        if rs is not None and epi != hip.EPI_QKV_ROPE:
+            kw["row_scale"] = rs
         if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES, hip.EPI_QKV_ROPE):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
         if epi in (hip.EPI_BIAS_SCALE_RES, hip.EPI_RES):
@@ -56,7 +63,7 @@ def main():
             sin, cos = (f(ang).repeat_interleave(2, -1).contiguous() for f in (torch.sin, torch.cos))
 
             def call():
-                assert ops.gemm_qkv_rope(a, w, kw["bias"], out, Q_, K_, sin, cos, H, hd, 1025, 1088, 1, 0.18, V=V_)
+                assert ops.gemm_qkv_rope(a, w, kw["bias"], out, Q_, K_, sin, cos, H, hd, 1025, 1088, 1, 0.18, V=V_, row_scale=rs)
         else:
             def call():
                 ops.gemm(a, w, out, epi, **kw)
