@@ -8,7 +8,7 @@
 //   * K rows are fed in a permuted order (bits 2<->3 of the row index swapped) which makes the accumulator
 //     registers 8t..8t+7 of that lane exactly the kv = 16t + 8h + (0..7) slice the PV MFMA wants as its B operand:
 //     P goes exp2 -> bf16 pack -> MFMA operand without leaving the lane;
-//   * V is stored transposed (Vt [hd][kv], written by the qkv_post kernels) so O^T = Vt P^T takes Vt rows as plain
+//   * gar_attention takes V transposed (Vt [hd][kv]; the f32 ViT path) so O^T = Vt P^T takes Vt rows as plain
 //     16-byte A fragments; O^T lands as lane (q, h) <- 16 d values: the per-query rescale is per-lane too.
 // K / Vt tiles are staged in LDS (XOR-swizzled 16-byte chunks, ds_read_b128 conflict-free for these access sets),
 // register-prefetched one tile ahead (issue loads -> compute current tile -> write next tile -> barrier).
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 // ===============================================================================================================
 // f32 (parity mode) — v_mfma_f32_32x32x2_f32; lane (i = lane&31, k = lane>>5) supplies A[i][k] / B[k][i]
 // ===============================================================================================================
-template <int HD, bool CAUSAL>
+// VROW: V row-major [kv][HD] (the KV cache's layout); the tile is transposed on its way into LDS.
+template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ Vt, float* __restrict__ O, int Hq,
                                                        int Hkv, int q_len, int q_pad, int kv_len_arg, int kv_stride,
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     const int coff = kv_len - q_len;
     const float* Qp = Q + (((int64_t)b * Hq + head) * q_pad) * HD;
     const float* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const float* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const float* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;       // same slab offset in either layout
     float qf[HD / 2];
     {
         const int qrow = min(q0 + l31, q_pad - 1);
@@ -288,11 +289,21 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
             float* d = ks + row * KLD + c4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        for (int idx = tid; idx < HD * 16; idx += 256) {
-            const int row = idx / 16, c4 = (idx % 16) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(Vp + (int64_t)row * kv_stride + kv0 + c4);
-            float* d = vs + row * VLD + c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (VROW) {
+            for (int idx = tid; idx < 64 * (HD / 4); idx += 256) {
+                const int row = idx / (HD / 4), c4 = (idx % (HD / 4)) * 4;
+                const int kvr = min(kv0 + row, kv_stride - 1);
+                const float4 v = *reinterpret_cast<const float4*>(Vp + (int64_t)kvr * HD + c4);
+                float* d = vs + c4 * VLD + row;
+                d[0] = v.x; d[VLD] = v.y; d[2 * VLD] = v.z; d[3 * VLD] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < HD * 16; idx += 256) {
+                const int row = idx / 16, c4 = (idx % 16) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(Vp + (int64_t)row * kv_stride + kv0 + c4);
+                float* d = vs + row * VLD + c4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
         }
         __syncthreads();
         const bool skip = !wave_active || (CAUSAL && kv0 > max(q0 + 31 + coff, kv_lo));
@@ -371,9 +382,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 template <int HD>
 static int launch_attn(int dtype, const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv,
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
-                       const int32_t* kv_start, hipStream_t s) {
+                       const int32_t* kv_start, hipStream_t s, bool vrow = false) {
     dim3 grid((q_len + 127) / 128, Hq, B), block(256);
-    if (dtype == GAR_BF16) {
+    if (dtype == GAR_F32 && vrow) {
+        const int lds = (64 * (HD + 1) + HD * 65) * 4;
+        if (causal)
+            hipLaunchKernelGGL((attn_f32_kernel<HD, true, true>), grid, block, lds, s, (const float*)Q, (const float*)K,
+                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
+        else
+            hipLaunchKernelGGL((attn_f32_kernel<HD, false, true>), grid, block, lds, s, (const float*)Q, (const float*)K,
+                               (const float*)Vt, (float*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start);
+    } else if (dtype == GAR_BF16) {
         const int lds = 2 * (64 * HD * 2 + HD * 128);
         if (causal)
             hipLaunchKernelGGL((attn_bf16_kernel<HD, true>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,
@@ -417,23 +436,33 @@ extern "C" int gar_attention(int dtype, const void* Q, const void* K, const void
 }
 
 
-// Same attention with V row-major [B, Hkv, kv_stride, hd] — the layout K has, and the one the fused qkv GEMM epilogue
-// writes (gar_gemm_params.qkv_v) — read through the transposing LDS load of gfx950: no transpose pass over V.
-// bf16, head_dim 64 / 96 / 128; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
+// Same attention with V row-major [B, Hkv, kv_stride, hd] — the layout K has, the one the fused qkv GEMM epilogues
+// write (gar_gemm_params.qkv_v) and the one the Llama KV cache keeps — read through the transposing LDS load of gfx950:
+// no transpose pass over V. bf16: head_dim 64 / 96 / 128; f32 (parity mode): head_dim 64 / 128, kv_prefix = 0, the tile is
+// transposed while it is staged. GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
 extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv,
                                   int hd, int q_len, int q_pad, int kv_len, int kv_stride, int causal,
                                   const int32_t* kv_len_dev, const int32_t* kv_start, int kv_prefix, gar_stream_t stream) {
+    GAR_CHECK_ARG(dtype == GAR_F32 || dtype == GAR_BF16, "attention_vrow: bad dtype");
     GAR_CHECK_ARG(Q && K && V && O, "attention_vrow: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_vrow: bad heads %d/%d", Hq, Hkv);
     GAR_CHECK_ARG(q_len > 0 && q_pad >= q_len && kv_stride % 64 == 0, "attention_vrow: bad lengths");
     GAR_CHECK_ARG(kv_len_dev || (kv_len > 0 && kv_len <= kv_stride && (!causal || kv_len >= q_len)),
                   "attention_vrow: kv_len %d out of range (stride %d, q_len %d)", kv_len, kv_stride, q_len);
-    GAR_CHECK_ARG(kv_prefix == 0 || (kv_prefix == 1 && !causal && !kv_len_dev && kv_len > 1),
-                  "attention_vrow: kv_prefix is 0 or 1 (non-causal, kv_len > 1)");
+    GAR_CHECK_ARG(kv_prefix == 0 || (kv_prefix == 1 && !causal && !kv_len_dev && kv_len > 1 && dtype == GAR_BF16),
+                  "attention_vrow: kv_prefix is 0 or 1 (bf16, non-causal, kv_len > 1)");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_F32 && (hd == 64 || hd == 128)) {
+        if (hd == 64) launch_attn<64>(dtype, Q, K, V, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, kv_start, s, true);
+        else launch_attn<128>(dtype, Q, K, V, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, kv_start, s, true);
+        GAR_CHECK_LAUNCH();
+        return GAR_OK;
+    }
     if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
         !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,
-                              kv_prefix, (hipStream_t)stream)) {
-        gar_set_error("attention_vrow: built for bf16, head_dim 64 / 96 / 128 (dtype %d, head_dim %d)", dtype, hd);
+                              kv_prefix, s)) {
+        gar_set_error("attention_vrow: built for bf16 head_dim 64 / 96 / 128 (kv slab < 2 GiB) and f32 head_dim 64 / 128 "
+                      "(dtype %d, head_dim %d)", dtype, hd);
         return GAR_ERR_UNSUPPORTED;
     }
     GAR_CHECK_LAUNCH();

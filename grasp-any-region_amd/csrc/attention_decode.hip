@@ -1,13 +1,14 @@
 // Decode attention (q_len = 1): split-KV, GQA-aware, HBM-bound.
 //
 //   Block = 4 waves = one (split, kv head, batch). The G = Hq/Hkv query heads sharing a kv head are the columns of
-//   the MFMA B operand (columns >= G are zero), so K and Vt of that kv head stream from HBM exactly ONCE per step.
-//   The block's kv range is cut in 64-kv tiles dealt round-robin to its waves; each wave loads its K / Vt MFMA
-//   fragments straight from global memory into VGPRs (no reuse across waves -> no LDS round trip), one tile AHEAD of
-//   the tile it is computing (register double buffering), keeps an online softmax, and the four waves are merged in
-//   LDS into one un-normalised partial (m, l, O[G][HD]) per block. decode_combine_kernel merges the splits.
+//   the MFMA B operand (columns >= G are zero), so K and V of that kv head stream from HBM exactly ONCE per step.
+//   The block's kv range is cut in 64-kv tiles dealt round-robin to its waves; each wave brings its K / V tiles — both
+//   row-major [kv][HD], the cache's layout — into a private LDS region with `buffer_load ... lds` DMA, forms the QK^T
+//   fragments with ds_read_b128 and the PV fragments (k = kv: a column of the V tile) with gfx950's transposing
+//   ds_read_b64_tr_b16, keeps an online softmax, and the four waves are merged in LDS into one un-normalised partial
+//   (m, l, O[G][HD]) per block. decode_combine_kernel merges the splits.
 //   kv length comes from device memory so the captured hipGraph replays unchanged for every token.
-//   Algorithmic bytes per launch: B * Hkv * kv_len * HD * 2 (K and Vt) * sizeof(bf16).
+//   Algorithmic bytes per launch: B * Hkv * kv_len * HD * 2 (K and V) * sizeof(bf16).
 #include <stdlib.h>
 
 #include "common.h"
@@ -20,193 +21,31 @@ __device__ __forceinline__ unsigned int cvt_pk_d(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
-template <int HD>
-struct Frags {
-    bf16x8 k[2][HD / 16];
-    bf16x8 v[HD / 32][4];
-};
-
-template <int HD>
-__device__ __forceinline__ void load_frags(Frags<HD>& f, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp,
-                                           int kv0, int kv_stride, int prow, int l31, int h) {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int row = min(kv0 + blk * 32 + prow, kv_stride - 1);
-#pragma unroll
-        for (int kd = 0; kd < HD / 16; ++kd)
-            f.k[blk][kd] = __builtin_nontemporal_load(
-                reinterpret_cast<const bf16x8*>(Kp + (int64_t)row * HD + kd * 16 + h * 8));
-    }
-#pragma unroll
-    for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            f.v[d][c] = __builtin_nontemporal_load(
-                reinterpret_cast<const bf16x8*>(Vp + (int64_t)(d * 32 + l31) * kv_stride + kv0 + c * 16 + h * 8));
-}
-
-template <int HD>
-__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void decode_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ Vt, float* __restrict__ part,
-                                                               int Hq, int Hkv, int kv_stride,
-                                                               const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
-                                                               bf16_t* __restrict__ O_direct) {
-    constexpr int NKD = HD / 16, NDB = HD / 32;
-    __shared__ float red[4][8][HD + 2];           // per wave: O[g][d], m, l   (g < G <= 8)
-    const int kv_len = kv_len_dev[0];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, b = blockIdx.z;
-    const int G = Hq / Hkv;
-    const int ntiles = (kv_len + 63) / 64;
-    // left-padded batch: sequence b lives in cache rows kv_lo .. kv_len - 1; the splits divide THAT range
-    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
-    const int t_lo = kv_lo >> 6;
-    const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
-    const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
-    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
-    bf16x8 qf[NKD];
-    {
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd)
-            qf[kd] = l31 < G ? *reinterpret_cast<const bf16x8*>(qp + kd * 16 + h * 8) : z;
-    }
-    f32x16 o[NDB];
-#pragma unroll
-    for (int d = 0; d < NDB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](const Frags<HD>& f, int tt_) {
-        const int kv0 = tt_ * 64;
-        f32x16 s[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int kd = 0; kd < NKD; ++kd)
-                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
-        if (kv0 + 64 > kv_len || kv0 < kv_lo) {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                    s[blk][r] = (kv < kv_len && kv >= kv_lo) ? s[blk][r] : -INFINITY;
-                }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        float ps = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[blk][r] - m_use); ps += p[r]; }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                u32x4 w;
-                w[0] = cvt_pk_d(p[tt * 8 + 0], p[tt * 8 + 1]);
-                w[1] = cvt_pk_d(p[tt * 8 + 2], p[tt * 8 + 3]);
-                w[2] = cvt_pk_d(p[tt * 8 + 4], p[tt * 8 + 5]);
-                w[3] = cvt_pk_d(p[tt * 8 + 6], p[tt * 8 + 7]);
-                pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
-            }
-        }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
-        }
-    };
-    // register double buffering: fragments of the wave's NEXT tile are in flight while the current one is computed
-    Frags<HD> fa, fb;
-    int t = t0 + wave;
-    if (t < t1) load_frags<HD>(fa, Kp, Vp, t * 64, kv_stride, prow, l31, h);
-    for (; t < t1; t += 8) {
-        const bool has_b = t + 4 < t1;
-        if (has_b) load_frags<HD>(fb, Kp, Vp, (t + 4) * 64, kv_stride, prow, l31, h);
-        compute(fa, t);
-        if (has_b) {
-            if (t + 8 < t1) load_frags<HD>(fa, Kp, Vp, (t + 8) * 64, kv_stride, prow, l31, h);
-            compute(fb, t + 4);
-        }
-    }
-    // ---- merge the four waves (LDS), one partial per block
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (l31 < G) {
-        float* pp = &red[wave][l31][0];
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pp[d * 32 + g4 * 8 + h * 4 + e] = o[d][g4 * 4 + e];
-        if (h == 0) { pp[HD] = m_run; pp[HD + 1] = l_tot; }
-    }
-    __syncthreads();
-    // thread (g = tid / 64 ... ) : G*HD outputs, 256 threads
-    for (int idx = tid; idx < G * HD; idx += 256) {
-        const int g = idx / HD, d = idx % HD;
-        float m = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w][g][HD]);
-        const float m_use = m == -INFINITY ? 0.f : m;
-        float acc = 0.f, l = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float sc = __builtin_amdgcn_exp2f(red[w][g][HD] - m_use);
-            acc += sc * red[w][g][d];
-            l += sc * red[w][g][HD + 1];
-        }
-        if (O_direct) {      // a single split: this IS the result (what decode_combine_kernel computes for nsplit = 1)
-            const float inv = l > 0.f ? 1.0f / l : 0.f;
-            O_direct[((int64_t)b * Hq + kvh * G + g) * HD + d] = f2bf(acc * inv);
-            continue;
-        }
-        float* pp = part + ((((int64_t)b * Hkv + kvh) * nsplit + split) * G + g) * (HD + 2);
-        pp[d] = acc;
-        if (d == 0) { pp[HD] = m; pp[HD + 1] = l; }
-    }
+typedef short tr4_d __attribute__((ext_vector_type(4)));
+// PV A-operand fragment (rows = d, k = 8 consecutive kv) out of a row-major V tile in LDS: two transposing reads, each a
+// [4 kv][16 d] block per 16-lane group (see attention_bf16.hip, VROW); `p` = this lane's chunk address for kv rows 0..3
+__device__ __forceinline__ bf16x8 v_frag_tr(const char* p, int row4_bytes) {
+    const tr4_d lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_d*)(p));
+    const tr4_d hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_d*)(p + row4_bytes));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-staged variant (head_dim 64): same math and work split, but every wave brings its 64-kv K / Vt tiles in with
-// `buffer_load_dwordx4 ... lds` — 1 KiB per instruction, eight full 128-byte lines — instead of per-lane fragment
-// loads that touch 32 different lines (32 B each) per instruction; measured with the compute removed the fragment
-// loads top out at 3.3 TB/s. A wave owns a private 16 KiB LDS region (K tile | Vt tile, XOR-swizzled through the
-// DMA source offsets like attention_bf16.hip): wait for tile t, pull its fragments into registers, immediately re-arm
-// the region with the DMA of the wave's next tile, then compute on the registers — no block-level barrier in the loop.
+// head_dim 64: every wave brings its 64-kv K / V tiles in with `buffer_load_dwordx4 ... lds` — 1 KiB per instruction,
+// eight full 128-byte lines (per-lane fragment loads from global memory touch 32 different lines, 32 B each, per
+// instruction: measured with the compute removed they top out at 3.3 TB/s). A wave owns a private 16 KiB LDS region
+// (K tile | V tile, XOR-swizzled through the DMA source offsets like attention_bf16.hip): wait for tile t, pull its
+// fragments into registers, immediately re-arm the region with the DMA of the wave's next tile, then compute on the
+// registers — no block-level barrier in the loop.
 // 64 KiB + merge buffer per block -> two blocks (8 waves) per CU, 128 KiB of loads in flight per CU.
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
 __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                 const bf16_t* __restrict__ Vt, float* __restrict__ part,
+                                                                 const bf16_t* __restrict__ V, float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
                                                                  const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                  bf16_t* __restrict__ O_direct) {
     constexpr int HD = 64, NKD = HD / 16, NDB = HD / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | Vt 8 KiB] then red
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | V 8 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 16384);
     const int kv_len = kv_len_dev[0];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -221,34 +60,30 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
     const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
     char* ks = smem + wave * 16384;
     char* vs = ks + 8192;
-    // DMA piece i = rows 8i .. 8i+7 of the tile (1 KiB, lane-linear in LDS); row r keeps its 16-byte chunk c at
-    // position c ^ key(r), key(r) = (r >> 1) & 7 = (lane >> 4) | ((i & 1) << 2)
+    // DMA piece i = rows 8i .. 8i+7 of the tile (1 KiB, lane-linear in LDS). K: row r keeps its 16-byte chunk c at
+    // position c ^ key(r), key(r) = (r >> 1) & 7 = (lane >> 4) | ((i & 1) << 2). V: chunk c at c ^ 4 ((r >> 1) & 1) — the
+    // four rows of a transposing read's block then cover all 64 banks once (attention_bf16.hip) — the same for every piece
     const int sub = lane >> 3, chunk = lane & 7, kq = lane >> 4;
-    int offK[2], offV[2];
+    int offK[2];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int c = chunk ^ (kq | (par << 2));
-        offK[par] = sub * 128 + (c << 4);
-        offV[par] = (int)((unsigned)sub * (unsigned)kv_stride * 2u) + (c << 4);
-    }
+    for (int par = 0; par < 2; ++par) offK[par] = sub * 128 + ((chunk ^ (kq | (par << 2))) << 4);
+    const int offV = sub * 128 + ((chunk ^ (((sub >> 1) & 1) << 2)) << 4);
     auto stage = [&](int t) {
-        const unsigned kbase = (unsigned)t * 64u * 128u;        // 64 kv rows of 128 B
-        const unsigned vbase = (unsigned)t * 128u;              // 64 kv columns
+        const unsigned base = (unsigned)t * 64u * 128u;         // 64 kv rows of 128 B, K and V alike
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + i * 1024), 16,
-                                                     offK[i & 1] + (int)(kbase + (unsigned)i * 1024u), 0, 0, 0);
+                                                     offK[i & 1] + (int)(base + (unsigned)i * 1024u), 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + i * 1024), 16,
-                                                     offV[i & 1] + (int)(vbase + (unsigned)i * 8u * (unsigned)kv_stride * 2u),
-                                                     0, 0, 0);
+                                                     offV + (int)(base + (unsigned)i * 1024u), 0, 0, 0);
     };
     bf16x8 qf[NKD];
     {
@@ -273,6 +108,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
         koff[blk] = row * 128;
         kkey[blk] = (row >> 1) & 7;
     }
+    // this lane's chunk of its 16-lane group's [4 kv][16 d] block: kv row 8h + (i >> 2) of a 16-kv step, d columns
+    // 16 ((lane >> 4) & 1) + 4 (i & 3) of a 32-d block; d-block 1 = chunk index + 4 = ^ 64 bytes
+    int vtr;
+    {
+        const int i = lane & 15, r = 8 * h + (i >> 2), col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+        vtr = r * 128 + ((((col >> 3) ^ (((r >> 1) & 1) << 2)) << 4) | ((col & 7) << 1));
+    }
 
     int t = t0 + wave;
     if (t < t1) stage(t);
@@ -285,13 +127,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
             for (int kd = 0; kd < NKD; ++kd)
                 kf[blk][kd] = *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            const int row = d * 32 + l31;
-            const int key = (row >> 1) & 7;
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-                vf[d][c4] = *reinterpret_cast<const bf16x8*>(vs + row * 128 + (((c4 * 2 + h) ^ key) << 4));
-        }
+            for (int c4 = 0; c4 < 4; ++c4) vf[d][c4] = v_frag_tr(vs + c4 * 16 * 128 + (vtr ^ (d << 6)), 4 * 128);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (t + 4 < t1) stage(t + 4);            // re-arm the region: its fragments are in registers now
@@ -351,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
         }
     }
-    // ---- merge the four waves (LDS), one partial per block — identical to decode_attn_bf16_kernel
+    // ---- merge the four waves (LDS), one partial per block
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (l31 < G) {
         float* pp = &red[wave][l31][0];
@@ -389,19 +227,19 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-staged variant for head_dim 128 (Llama-3.1-8B): a 64-kv tile is 16 KiB of K (256-byte rows) + 16 KiB of Vt per wave.
+// head_dim 128 (Llama-3.1-8B): a 64-kv tile is 16 KiB of K (256-byte rows) + 16 KiB of V per wave.
 // Pulling both into registers before re-arming the region (what the head_dim-64 kernel does) would need 128 VGPRs of
-// fragments on top of the 64 of O, so K and Vt are two phases with their own DMA groups and counted waits:
-//   wait K(t) [vmcnt: the 16 Vt pieces behind it may stay out] -> K fragments -> re-arm K with tile t+4 -> QK^T, softmax
-//   wait Vt(t) [the 16 K pieces just issued may stay out]      -> Vt fragments -> re-arm Vt            -> PV
+// fragments on top of the 64 of O, so K and V are two phases with their own DMA groups and counted waits:
+//   wait K(t) [vmcnt: the 16 V pieces behind it may stay out] -> K fragments -> re-arm K with tile t+4 -> QK^T, softmax
+//   wait V(t) [the 16 K pieces just issued may stay out]      -> V fragments -> re-arm V             -> PV
 // 128 KiB + merge buffer per block: one block (4 waves) per CU, the same 128 KiB of loads in flight per CU.
 __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                    const bf16_t* __restrict__ Vt, float* __restrict__ part,
+                                                                    const bf16_t* __restrict__ V, float* __restrict__ part,
                                                                     int Hq, int Hkv, int kv_stride,
                                                                     const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                     bf16_t* __restrict__ O_direct) {
     constexpr int HD = 128, NKD = HD / 16, NDB = HD / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | Vt 16 KiB] then red
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | V 16 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 32768);
     const int kv_len = kv_len_dev[0];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -416,27 +254,23 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
     const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
     const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
     const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;
+    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
     char* ks = smem + wave * 32768;
     char* vs = ks + 16384;
     // K piece i = rows 4i .. 4i+3 (256 B each); row r keeps its 16-byte chunk c at position c ^ (r & 15)
-    // Vt piece i = d-rows 8i .. 8i+7 (128 B = 64 kv each); row r keeps chunk c at c ^ ((r >> 1) & 7)
-    int offK[4], offV[2];
+    // V piece i = rows 4i .. 4i+3 too; row r keeps chunk c at c ^ 4 (r & 3): the four rows of a transposing read's block are
+    // 256 B apart and take the four 64-byte bank groups (attention_bf16.hip) — the same offsets for every piece
+    int offK[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
         const int r = lane >> 4;                                    // row inside the piece
         const int c = (lane & 15) ^ ((q4 * 4 + r) & 15);
         offK[q4] = r * 256 + (c << 4);
     }
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int sub = lane >> 3;
-        const int c = (lane & 7) ^ ((lane >> 4) | (par << 2));
-        offV[par] = (int)((unsigned)sub * (unsigned)kv_stride * 2u) + (c << 4);
-    }
+    const int offV = (lane >> 4) * 256 + (((lane & 15) ^ ((lane >> 4) << 2)) << 4);
     auto stageK = [&](int t) {
         const unsigned kbase = (unsigned)t * 64u * 256u;        // 64 kv rows of 256 B
 #pragma unroll
@@ -445,12 +279,11 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                                                      offK[i & 3] + (int)(kbase + (unsigned)i * 1024u), 0, 0, 0);
     };
     auto stageV = [&](int t) {
-        const unsigned vbase = (unsigned)t * 128u;              // 64 kv columns
+        const unsigned vbase = (unsigned)t * 64u * 256u;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + i * 1024), 16,
-                                                     offV[i & 1] + (int)(vbase + (unsigned)i * 8u * (unsigned)kv_stride * 2u),
-                                                     0, 0, 0);
+                                                     offV + (int)(vbase + (unsigned)i * 1024u), 0, 0, 0);
     };
     bf16x8 qf[NKD];
     {
@@ -475,12 +308,17 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
         koff[blk] = row * 256;
         kkey[blk] = row & 15;
     }
+    int vtr;            // see decode_attn_lds_kernel; 256-byte rows, chunk key 4 (r & 3)
+    {
+        const int i = lane & 15, r = 8 * h + (i >> 2), col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+        vtr = r * 256 + ((((col >> 3) ^ ((r & 3) << 2)) << 4) | ((col & 7) << 1));
+    }
 
     int t = t0 + wave;
     if (t < t1) { stageK(t); stageV(t); }
     for (; t < t1; t += 4) {
         const bool more = t + 4 < t1;
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K(t) landed; the 16 Vt(t) pieces may still be out
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K(t) landed; the 16 V(t) pieces may still be out
         f32x16 s[2];
         {
             bf16x8 kf[2][NKD];
@@ -537,18 +375,14 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
             }
         }
         l_run = l_run * alpha + ps;
-        // Vt(t): everything issued before K(t+4) has to be in; the 16 K pieces just issued may stay out
+        // V(t): everything issued before K(t+4) has to be in; the 16 K pieces just issued may stay out
         if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bf16x8 vf[NDB][4];
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            const int row = d * 32 + l31;
-            const int key = (row >> 1) & 7;
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-                vf[d][c4] = *reinterpret_cast<const bf16x8*>(vs + row * 128 + (((c4 * 2 + h) ^ key) << 4));
-        }
+            for (int c4 = 0; c4 < 4; ++c4) vf[d][c4] = v_frag_tr(vs + c4 * 16 * 256 + (vtr ^ (d << 6)), 4 * 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (more) stageV(t + 4);
@@ -564,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
         }
     }
-    // ---- merge the four waves (LDS), one partial per block — identical to decode_attn_bf16_kernel
+    // ---- merge the four waves (LDS), one partial per block — as in decode_attn_lds_kernel
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (l31 < G) {
         float* pp = &red[wave][l31][0];
@@ -633,22 +467,26 @@ extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max
     return (int64_t)B * Hq * max_splits * (hd + 2) * 4;
 }
 
-extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq,
+extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq,
                                     int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
                                     int max_splits, void* workspace, gar_stream_t stream) {
-    GAR_CHECK_ARG(q && Kc && Vtc && O && kv_len_dev, "attention_decode: null pointer");
+    GAR_CHECK_ARG(q && Kc && Vc && O && kv_len_dev, "attention_decode: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
     GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
     GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
     if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
-        return gar_attention(dtype, q, Kc, Vtc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, stream);
+        return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, 0, stream);
     GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
+    if ((int64_t)Smax * hd * 2 >= ((int64_t)1 << 31)) {       // one (sequence, kv head) slab has to fit a buffer descriptor
+        gar_set_error("attention_decode: Smax %d x head_dim %d exceeds the 2 GiB per-slab range of the DMA-staged kernels", Smax, hd);
+        return GAR_ERR_UNSUPPORTED;
+    }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(max_splits, Hkv, B);
     // one split per (sequence, kv head): the attention kernel normalises and writes O itself, no combine launch
     bf16_t* direct = max_splits == 1 ? (bf16_t*)O : nullptr;
-    if (hd == 64 && (int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {      // DMA-staged kernel; else per-lane fragment loads
+    if (hd == 64) {
         constexpr int lds = 4 * 16384 + 4 * 8 * (64 + 2) * 4;
         static gar_once_per_device attr_once;
         if (attr_once.first()) {
@@ -656,17 +494,11 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
         hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
+                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
-    } else if (hd == 64) {
-        hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
-        if (!direct)
-            hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
-                               (bf16_t*)O, Hq, Hkv, max_splits);
-    } else if ((int64_t)Smax * hd * 2 < ((int64_t)1 << 31)) {
+    } else {
         constexpr int lds = 4 * 32768 + 4 * 8 * (128 + 2) * 4;
         static gar_once_per_device attr_once;
         if (attr_once.first()) {
@@ -674,13 +506,7 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
         hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
-        if (!direct)
-            hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
-                               (bf16_t*)O, Hq, Hkv, max_splits);
-    } else {
-        hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vtc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
+                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);

@@ -330,7 +330,7 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
     GAR_CHECK_ARG(pp != nullptr, "gar_gemm: null params");
     const gar_gemm_params& p = *pp;
     GAR_CHECK_ARG(dtype == GAR_F32 || dtype == GAR_BF16, "gar_gemm: bad dtype %d", dtype);
-    GAR_CHECK_ARG(p.A && p.W && p.C, "gar_gemm: null operand");
+    GAR_CHECK_ARG(p.A && p.W && (p.C || p.epilogue == GAR_EPI_QKV_ROPE_LLM), "gar_gemm: null operand");
     GAR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gar_gemm: bad shape %d %d %d", p.M, p.N, p.K);
     const int kq = dtype == GAR_BF16 ? 64 : 16;
     GAR_CHECK_ARG(p.K % kq == 0, "gar_gemm: K=%d must be a multiple of %d", p.K, kq);
@@ -360,6 +360,16 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
                       "gar_gemm: QKV_ROPE args");
     if (e == GAR_EPI_QKV_ROPE)      // the compact (sin, cos)-pair table goes with the per-wave epilogue, which writes v head-major
         GAR_CHECK_ARG(p.qkv_cos || p.qkv_v, "gar_gemm: QKV_ROPE with the compact table (qkv_cos == NULL) needs qkv_v");
+    if (e == GAR_EPI_QKV_ROPE_LLM) {
+        const int hd_ = p.qkv_head_dim;
+        GAR_CHECK_ARG(!p.bias && p.qkv_q && p.qkv_k && p.qkv_v && p.qkv_sin && p.qkv_cos && p.qkv_heads > 0 && p.qkv_kv_heads > 0 &&
+                          (hd_ == 64 || hd_ == 128) && p.N == (p.qkv_heads + 2 * p.qkv_kv_heads) * hd_ && p.qkv_tokens > 0 &&
+                          p.M % p.qkv_tokens == 0 && p.qkv_tokens_pad >= p.qkv_tokens && p.qkv_kv_stride > 0 && p.qkv_pos0 >= 0 &&
+                          (p.qkv_pos_dev || p.qkv_pos0 + p.qkv_tokens <= p.qkv_kv_stride) &&
+                          (int64_t)p.qkv_heads * p.qkv_tokens_pad * hd_ < ((int64_t)1 << 31) &&
+                          (int64_t)p.qkv_kv_heads * p.qkv_kv_stride * hd_ < ((int64_t)1 << 31),
+                      "gar_gemm: QKV_ROPE_LLM args");
+    }
     if (e == GAR_EPI_PATCH_POS)
         GAR_CHECK_ARG(p.pos && p.tokens_in > 0 && p.tokens_out >= p.tokens_in + p.token_offset && p.N % 4 == 0,
                       "gar_gemm: PATCH_POS args");
@@ -378,6 +388,15 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
             // keeps GAR_EPI_BIAS + gar_vit_qkv_post
             if (dtype != GAR_BF16 || !gar_gemm_pp_try(p, s)) {
                 gar_set_error("gar_gemm: QKV_ROPE epilogue is built for the bf16 ping-pong kernel only (M=%d N=%d)", p.M, p.N);
+                return GAR_ERR_UNSUPPORTED;
+            }
+            rc = GAR_OK;
+            break;
+        case GAR_EPI_QKV_ROPE_LLM:
+            // fused gar_llm_qkv_post: bf16, shapes the ping-pong kernel takes; otherwise the caller keeps GAR_EPI_NONE +
+            // gar_llm_qkv_post (with W in its natural row order)
+            if (dtype != GAR_BF16 || !gar_gemm_pp_try(p, s)) {
+                gar_set_error("gar_gemm: QKV_ROPE_LLM epilogue is built for the bf16 ping-pong kernel only (M=%d N=%d)", p.M, p.N);
                 return GAR_ERR_UNSUPPORTED;
             }
             rc = GAR_OK;

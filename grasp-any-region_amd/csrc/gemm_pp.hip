@@ -207,7 +207,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                EPI == GAR_EPI_QKV_ROPE;
     // epilogues that can consume a folded norm (row_scale) / produce the statistics of one (row_stats)
     constexpr bool RS_EPI = !GATHER && (EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU ||
-                                        EPI == GAR_EPI_SWIGLU || EPI == GAR_EPI_QKV_ROPE);
+                                        EPI == GAR_EPI_SWIGLU || EPI == GAR_EPI_QKV_ROPE ||
+                                        EPI == GAR_EPI_QKV_ROPE_LLM);
     constexpr bool STATS_EPI = EPI == GAR_EPI_RES || EPI == GAR_EPI_BIAS_SCALE_RES;
     const bool RS = RS_EPI && p.row_scale != nullptr;                      // uniform over the launch
     u32x4 bias_cur[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
@@ -544,9 +545,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // wave's strip are consecutive and span at most two image tiles when a tile has >= 128 tokens: ONE integer division
         // per strip and a compare / select per row instead of a ~25-instruction division per row (32 per lane and tile —
         // as many VALU instructions as the rest of the QKV_ROPE epilogue)
-        const int TT = EPI == GAR_EPI_QKV_ROPE ? p.qkv_tokens : (EPI == GAR_EPI_PATCH_POS ? p.tokens_in : 1);
+        const int TT = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_QKV_ROPE_LLM) ? p.qkv_tokens
+                                                                                : (EPI == GAR_EPI_PATCH_POS ? p.tokens_in : 1);
         const int mw = m0 + wm * 128;
-        const int tile_w = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_PATCH_POS) ? mw / TT : 0;
+        const int tile_w = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_QKV_ROPE_LLM || EPI == GAR_EPI_PATCH_POS) ? mw / TT : 0;
         const int tok_w = mw - tile_w * TT;
         auto split_row = [&](int m, int& tile, int& tok) {
             if (TT >= 128) {
@@ -614,6 +616,51 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             const int rt = max(tok - p.qkv_prefix, 0);
             return *reinterpret_cast<const u32x4*>(sc_P0 + rt * p.qkv_head_dim + half * 4);
         };
+        // QKV_ROPE_LLM (HF Llama): half-split RoPE — the partner of dim d is d +- hd/2, which the W row order (gar_hip.h) puts
+        // 32 columns away in the SAME 64-column strip: lanes (rr, c) and (rr, c + 4), c < 4, both read x1 = columns 8c.. and
+        // x2 = columns 32 + 8c.. of the wave's fp32-staged row; the first computes x1 cos - x2 sin, the second x2 cos + x1 sin.
+        // Both need the same 8 cos and 8 sin values: the first lane loads the cos, the second the sin (each times the q scale),
+        // and one ds_swizzle (lane ^ 4) per value hands them over — half the loads and half the registers of the prefetch ring.
+        // A strip lies inside one head of one part, so `lpart` is wave-uniform.
+        constexpr bool QKVL = EPI == GAR_EPI_QKV_ROPE_LLM;
+        const int lHD = QKVL ? p.qkv_head_dim : 64, lHALF = lHD >> 1;
+        const int lDq = QKVL ? p.qkv_heads * lHD : 1, lDk = QKVL ? p.qkv_kv_heads * lHD : 1;
+        const int ns = n0 + wn * 64;                                    // first column of the strip (wave-uniform)
+        const int lpart = !QKVL ? 0 : (ns < lDq ? 0 : (ns < lDq + lDk ? 1 : 2));
+        const int lnn = ns - (lpart == 0 ? 0 : (lpart == 1 ? lDq : lDq + lDk));
+        const int lh = lnn / lHD, lj = (lnn - lh * lHD) >> 6;           // head, 64-column strip inside the head
+        const bool l_rot = QKVL && lpart < 2 && ns < p.N;
+        const int l_dh = 32 * lj + (ch & 3) * 8;                        // this lane's column in the [pos, hd/2] tables
+        const int l_d = lpart < 2 ? l_dh + (ch >= 4 ? lHALF : 0) : 64 * lj + ch * 8;
+        const float l_qm = lpart == 0 ? p.qkv_q_scale : 1.0f;
+        const float l_sg = ch >= 4 ? 1.0f : -1.0f;                      // first half: x1 c - x2 s; second half: x2 c + x1 s
+        const float* const l_tab = QKVL ? (ch >= 4 ? p.qkv_sin : p.qkv_cos) + l_dh : nullptr;
+        const int l_hp = lpart == 0 ? p.qkv_heads : p.qkv_kv_heads, l_tp = lpart == 0 ? p.qkv_tokens_pad : p.qkv_kv_stride;
+        const int l_p0 = !QKVL ? 0 : (p.qkv_pos_dev ? p.qkv_pos_dev[0] : p.qkv_pos0);
+        const int l_TS = QKVL ? l_hp * l_tp * lHD : 0;                  // elements per sequence of this part (< 2^31: checked on the host)
+        bf16_t* const l_P0 = !QKVL ? nullptr
+                                   : (bf16_t*)(lpart == 0 ? p.qkv_q : (lpart == 1 ? p.qkv_k : p.qkv_v)) +
+                                         (((int64_t)tile_w * l_hp + lh) * l_tp + (lpart ? l_p0 : 0)) * lHD + l_d;
+        const int l_nb = QKVL ? p.M / TT : 1;
+        const int l_lp0 = (QKVL && p.qkv_left_pad) ? p.qkv_left_pad[min(tile_w, l_nb - 1)] : 0;
+        const int l_lp1 = (QKVL && p.qkv_left_pad) ? p.qkv_left_pad[min(tile_w + 1, l_nb - 1)] : 0;
+        auto l_pos = [&](int i, int t) -> int {                         // RoPE position of slot (i, t)'s token
+            const int m = min(row_of(i, t), p.M - 1);
+            int tile, tok;
+            split_row(m, tile, tok);
+            const int lp = !p.qkv_left_pad ? 0 : (TT >= 128 ? (tile == tile_w ? l_lp0 : l_lp1) : p.qkv_left_pad[tile]);
+            return max(l_p0 + tok - lp, 0);
+        };
+        u32x4 lcs[2][2][2];                                             // [ring][t][values 0..3, 4..7] of this lane's table
+        auto l_load = [&](int i, int slot) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ro = l_pos(i, t) * lHALF;                     // < max_pos * hd / 2: fits 32 bits
+                lcs[slot][t][0] = *reinterpret_cast<const u32x4*>(l_tab + ro);
+                lcs[slot][t][1] = *reinterpret_cast<const u32x4*>(l_tab + ro + 4);
+            }
+        };
+        if (QKVL && l_rot) l_load(0, 0);
         u32x4 sc[2][2][2];
         if (QKV) {
 #pragma unroll
@@ -644,6 +691,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) sc[(i + 1) & 1][t][hf] = sc_load(i + 1, t, hf);
             }
+            if (QKVL && l_rot && i + 1 < 8) l_load(i + 1, (i + 1) & 1);
             if (DIRECT) {
 #pragma unroll
                 for (int jq = 0; jq < 2; ++jq) {
@@ -683,12 +731,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                f32x4 a2[2], b2[2];
+                f32x4 a2[2], b2[2], pa2[2], pb2[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int row = t * 8 + rr;
                     a2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2) ^ (row & 15)) << 4));
                     b2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2 + 1) ^ (row & 15)) << 4));
+                    if (QKVL && l_rot) {        // x1 = columns 8 (ch & 3).., x2 = the same 32 columns further, for both lanes of a pair
+                        const int c1 = ch & 3, c2 = c1 + 4;
+                        a2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c1 * 2) ^ (row & 15)) << 4));
+                        b2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c1 * 2 + 1) ^ (row & 15)) << 4));
+                        pa2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c2 * 2) ^ (row & 15)) << 4));
+                        pb2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c2 * 2 + 1) ^ (row & 15)) << 4));
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -714,7 +769,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                 }
                             }
                         }
-                        if (QKV) {
+                        if (QKVL) {
+                            int tile, tok;
+                            split_row(m, tile, tok);
+                            if (l_rot) {            // o (= x1 here) and x2; `mine` = cos (first-half lane) / sin (second-half lane)
+                                const f32x4 pa = pa2[t], pb = pb2[t];
+                                const float x2[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float mine = __uint_as_float(lcs[i & 1][t][e >> 2][e & 3]) * l_qm;
+                                    const float theirs = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mine), 0x101F));   // lane ^ 4
+                                    // first half:  x1 cos - x2 sin = x1 mine - x2 theirs;   second half: x2 cos + x1 sin = x2 theirs + x1 mine
+                                    o[e] = __builtin_fmaf(x2[e], theirs * l_sg, o[e] * mine);
+                                }
+                            }
+                            st8(l_P0 + ((tile - tile_w) * l_TS + tok * lHD), o);
+                        } else if (QKV) {
                             int tile, tok;
                             split_row(m, tile, tok);
                             if (any_rot) {          // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs; q also carries its scale
@@ -1097,7 +1167,7 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
     // folded norms: row_scale on the consumer epilogues, row_stats on the producers (include/gar_hip.h)
     const int e_ = p.epilogue;
     if (p.row_scale && !(e_ == GAR_EPI_NONE || e_ == GAR_EPI_BIAS || e_ == GAR_EPI_BIAS_GELU || e_ == GAR_EPI_SWIGLU ||
-                         (e_ == GAR_EPI_QKV_ROPE && !p.qkv_cos && p.qkv_v)))
+                         e_ == GAR_EPI_QKV_ROPE_LLM || (e_ == GAR_EPI_QKV_ROPE && !p.qkv_cos && p.qkv_v)))
         return false;
     if (p.row_stats && !(e_ == GAR_EPI_RES || e_ == GAR_EPI_BIAS_SCALE_RES)) return false;
     switch (p.epilogue) {
@@ -1109,6 +1179,7 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
         case GAR_EPI_SWIGLU: launch_pp<GAR_EPI_SWIGLU>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_PATCH_POS: launch_pp<GAR_EPI_PATCH_POS>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_QKV_ROPE: launch_pp<GAR_EPI_QKV_ROPE>(p, pm, pn, num_cus, s); break;
+        case GAR_EPI_QKV_ROPE_LLM: launch_pp<GAR_EPI_QKV_ROPE_LLM>(p, pm, pn, num_cus, s); break;
         default: return false;
     }
     return true;

@@ -1,23 +1,24 @@
 // Llama-side data movement kernels:
 //   llm_qkv_post   half-split RoPE (llama3-scaled tables) + q scale + head-major relayout + KV-cache append
-//                  (K [B,Hkv,Smax,hd], V transposed [B,Hkv,hd,Smax] so both attention kernels read 16-B MFMA fragments)
+//                  (K and V both [B,Hkv,Smax,hd]: one contiguous row per appended token; the attention kernels form the PV
+//                  operand with gfx950's transposing LDS read)
 //   embed_lookup   embedding rows of the just-sampled tokens
 //   argmax         greedy sampling with first-index tie break; writes into the device-side token matrix
 #include "common.h"
 
 // block = (batch b, 64-position chunk); loops over all heads of q, k, v.
-// thread (token nl = tid/ (HD/16), i8 = 8-wide slice of the FIRST half): rotates (x[i], x[i+HD/2]) pairs.
+// thread (token nl = tid/ (HD/16), i8 = 8-wide slice of the FIRST half): rotates (x[i], x[i+HD/2]) pairs of the q / k heads;
+// the v heads go through the same loop unrotated (cos = 1, sin = 0) into the row-major V cache.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__ qkv, const float* __restrict__ cs,
                                                            const float* __restrict__ sn, T* __restrict__ Q,
-                                                           T* __restrict__ Kc, T* __restrict__ Vtc, int S, int Spad,
+                                                           T* __restrict__ Kc, T* __restrict__ Vc, int S, int Spad,
                                                            int Hq, int Hkv, int Smax, int pos0,
                                                            const int32_t* __restrict__ pos_dev,
                                                            const int32_t* __restrict__ left_pad, float q_scale) {
     constexpr int HALF = HD / 2;
     constexpr int LPT = HALF / 8;               // lanes per token (4 for hd 64, 8 for hd 128)
     constexpr int TPP = 256 / LPT;              // tokens per pass (64 / 32)
-    __shared__ T vs[64 * (HD + 2)];
     const int chunks = (Spad + 63) / 64;
     const int ch = blockIdx.x % chunks;
     const int b = blockIdx.x / chunks;
@@ -27,9 +28,10 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
     // left-padded batch (HF generation): sequence b starts at row left_pad[b]; the CACHE row of a token stays its row in the
     // padded sequence, only its RoPE position is counted from the first real token (rows before it: position 0, never read)
     const int lp = left_pad ? left_pad[b] : 0;
-    const int W = (Hq + 2 * Hkv) * HD;
-    // rotary heads (q, k): a thread keeps its token and its 8-wide slice for every head, so cos / sin are loaded once per
-    // pass and the rows of RU heads are in flight together (a CU holds 16 waves: the latency cover has to come from here)
+    const int nh = Hq + 2 * Hkv;
+    const int W = nh * HD;
+    // a thread keeps its token and its 8-wide slice for every head, so cos / sin are loaded once per pass and the rows of
+    // RU heads are in flight together (a CU holds 16 waves: the latency cover has to come from here)
     constexpr int RU = 4;
     for (int pass = 0; pass < 64 / TPP; ++pass) {
         const int nl = pass * TPP + tid / LPT;
@@ -40,12 +42,12 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
             ld8(cs + (int64_t)rp * HALF + i8, c);
             ld8(sn + (int64_t)rp * HALF + i8, sv);
         }
-        for (int head0 = 0; head0 < Hq + Hkv; head0 += RU) {
+        for (int head0 = 0; head0 < nh; head0 += RU) {
             float x1[RU][8], x2[RU][8];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int head = head0 + u;
-                if (s < S && head < Hq + Hkv) {
+                if (s < S && head < nh) {
                     const T* row = qkv + ((int64_t)b * S + s) * W + head * HD;
                     ld8(row + i8, x1[u]);
                     ld8(row + HALF + i8, x2[u]);
@@ -57,9 +59,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int head = head0 + u;
-                if (head >= Hq + Hkv) break;
-                const bool isq = head < Hq;
-                if (s < S) {
+                if (head >= nh) break;
+                const bool isq = head < Hq, isv = head >= Hq + Hkv;
+                if (s < S && !isv) {
                     const float sc = isq ? q_scale : 1.0f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {   // q*cos + rotate_half(q)*sin
@@ -73,55 +75,13 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
                     T* o = Q + (((int64_t)b * Hq + head) * Spad + s) * HD;
                     st8(o + i8, x1[u]);
                     st8(o + HALF + i8, x2[u]);
-                } else if (!isq && s < S) {
-                    T* o = Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0 + s) * HD;
+                } else if (!isq && s < S) {         // k and v rows of the cache: [B, Hkv, Smax, HD] both
+                    T* o = (isv ? Vc + ((int64_t)b * Hkv + (head - Hq - Hkv)) * (int64_t)Smax * HD
+                                : Kc + ((int64_t)b * Hkv + (head - Hq)) * (int64_t)Smax * HD) + (int64_t)(p0 + s) * HD;
                     st8(o + i8, x1[u]);
                     st8(o + HALF + i8, x2[u]);
                 }
             }
-        }
-    }
-    // v heads: transposed into the cache through LDS
-    for (int head = Hq + Hkv; head < Hq + 2 * Hkv; ++head) {
-        for (int pass = 0; pass < 64 / TPP; ++pass) {
-            const int nl = pass * TPP + tid / LPT;
-            const int s = ch * 64 + nl;
-            float x1[8], x2[8];
-            if (s < S) {
-                const T* row = qkv + ((int64_t)b * S + s) * W + head * HD;
-                ld8(row + i8, x1);
-                ld8(row + HALF + i8, x2);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x1[e] = x2[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                DT<T>::st(&vs[nl * (HD + 2) + i8 + e], x1[e]);
-                DT<T>::st(&vs[nl * (HD + 2) + HALF + i8 + e], x2[e]);
-            }
-        }
-        {
-            __syncthreads();
-            const int hv = head - Hq - Hkv;
-            T* vbase = Vtc + ((int64_t)b * Hkv + hv) * HD * (int64_t)Smax;
-            const int col0 = p0 + ch * 64;
-            const int nvalid = min(64, S - ch * 64);
-            if ((col0 & 7) == 0 && nvalid == 64) {
-                for (int d = tid / 8; d < HD; d += 32) {
-                    const int n8 = (tid % 8) * 8;
-                    float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = DT<T>::ld(&vs[(n8 + e) * (HD + 2) + d]);
-                    st8(vbase + (int64_t)d * Smax + col0 + n8, o);
-                }
-            } else {                                   // ragged / unaligned (decode appends a single column)
-                for (int i = tid; i < HD * nvalid; i += 256) {
-                    const int d = i / nvalid, n = i % nvalid;
-                    vbase[(int64_t)d * Smax + col0 + n] = vs[n * (HD + 2) + d];
-                }
-            }
-            __syncthreads();
         }
     }
 }
@@ -130,7 +90,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __restrict__ qkv, const float* __restrict__ cs,
                                                                   const float* __restrict__ sn, T* __restrict__ Q,
-                                                                  T* __restrict__ Kc, T* __restrict__ Vtc, int B, int Spad,
+                                                                  T* __restrict__ Kc, T* __restrict__ Vc, int B, int Spad,
                                                                   int Hq, int Hkv, int Smax, int pos0,
                                                                   const int32_t* __restrict__ pos_dev,
                                                                   const int32_t* __restrict__ left_pad, float q_scale) {
@@ -164,19 +124,16 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
         st8(o + i8, x1);
         st8(o + HALF + i8, x2);
     } else {
-        T* vbase = Vtc + ((int64_t)b * Hkv + (head - Hq - Hkv)) * HD * (int64_t)Smax + p0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            DT<T>::st(vbase + (int64_t)(i8 + e) * Smax, x1[e]);
-            DT<T>::st(vbase + (int64_t)(HALF + i8 + e) * Smax, x2[e]);
-        }
+        T* o = Vc + (((int64_t)b * Hkv + (head - Hq - Hkv)) * Smax + p0) * HD;
+        st8(o + i8, x1);
+        st8(o + HALF + i8, x2);
     }
 }
 
 extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, const float* sn, void* Q, void* Kc,
-                                void* Vtc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
+                                void* Vc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
                                 const int32_t* pos_dev, const int32_t* left_pad, float q_scale, gar_stream_t stream) {
-    GAR_CHECK_ARG(qkv && cs && sn && Q && Kc && Vtc, "llm_qkv_post: null pointer");
+    GAR_CHECK_ARG(qkv && cs && sn && Q && Kc && Vc, "llm_qkv_post: null pointer");
     GAR_CHECK_ARG(B > 0 && S > 0 && Spad >= S && Smax % 64 == 0, "llm_qkv_post: bad shape");
     GAR_CHECK_ARG(pos_dev || pos0 + S <= Smax, "llm_qkv_post: cache overflow %d+%d > %d", pos0, S, Smax);
     GAR_CHECK_ARG(hd == 64 || hd == 128, "llm_qkv_post: head_dim %d not built (64, 128)", hd);
@@ -186,7 +143,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
         dim3 g1((total + 255) / 256), b1(256);
 #define LAUNCH_LQD(TT, HD_)                                                                                         \
     hipLaunchKernelGGL((llm_qkv_post_decode_kernel<TT, HD_>), g1, b1, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc, \
-                       (TT*)Vtc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
+                       (TT*)Vc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
         if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQD(bf16_t, 64); else LAUNCH_LQD(bf16_t, 128); }
         else { if (hd == 64) LAUNCH_LQD(float, 64); else LAUNCH_LQD(float, 128); }
 #undef LAUNCH_LQD
@@ -196,7 +153,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
     dim3 grid(B * ((Spad + 63) / 64)), block(256);
 #define LAUNCH_LQP(TT, HD_)                                                                                       \
     hipLaunchKernelGGL((llm_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc,  \
-                       (TT*)Vtc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
+                       (TT*)Vc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
     if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQP(bf16_t, 64); else LAUNCH_LQP(bf16_t, 128); }
     else { if (hd == 64) LAUNCH_LQP(float, 64); else LAUNCH_LQP(float, 128); }
 #undef LAUNCH_LQP

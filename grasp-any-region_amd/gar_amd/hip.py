@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
 
 GAR_F32, GAR_BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE = range(8)
+(EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
+ EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GarError(RuntimeError):
@@ -31,7 +32,9 @@ class GemmParams(C.Structure):
                 ("qkv_heads", C.c_int32), ("qkv_head_dim", C.c_int32), ("qkv_tokens", C.c_int32),
                 ("qkv_tokens_pad", C.c_int32), ("qkv_prefix", C.c_int32), ("qkv_q_scale", C.c_float),
                 ("split_k", C.c_int32), ("partial", C.c_void_p), ("qkv_v", C.c_void_p),
-                ("row_scale", C.c_void_p), ("row_stats", C.c_void_p)]
+                ("row_scale", C.c_void_p), ("row_stats", C.c_void_p),
+                ("qkv_kv_heads", C.c_int32), ("qkv_kv_stride", C.c_int32), ("qkv_pos0", C.c_int32),
+                ("qkv_pos_dev", C.c_void_p), ("qkv_left_pad", C.c_void_p)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -169,6 +169,9 @@ class GARModel:
     # carries gamma (and, for LayerNorm, centred rows), the producer GEMM's epilogue writes the row statistics — the
     # stand-alone norm passes (3.3 % of a step, at HBM bandwidth) disappear
     FOLD_NORMS = True
+    # bf16 with FOLD_NORMS: RoPE, q scale and the KV-cache append run in the Llama prefill qkv GEMM's epilogue
+    # (GAR_EPI_QKV_ROPE_LLM) — no [B*S, (Hq + 2 Hkv) hd] intermediate, no llm_qkv_post pass
+    LLM_QKV_EPILOGUE = True
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
@@ -342,6 +345,9 @@ class GARModel:
         self.layers = []
         F = t.intermediate_size
         assert F % 16 == 0
+        qkv_order = ops.llm_qkv_weight_order(t.head_dim, t.num_attention_heads, t.num_key_value_heads) \
+            if (fold and self.LLM_QKV_EPILOGUE and t.head_dim in (64, 128)) else torch.arange((t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim)
+        self.qkv_f_permuted = bool((qkv_order != torch.arange(qkv_order.numel())).any())
         for i in range(t.num_hidden_layers):
             b = f"{LM}layers.{i}."
             qkv = torch.cat([W[b + "self_attn.q_proj.weight"], W[b + "self_attn.k_proj.weight"],
@@ -351,7 +357,8 @@ class GARModel:
             gu = torch.stack([g.view(F // 16, 16, -1), u.view(F // 16, 16, -1)], dim=1).reshape(2 * F, -1)
             extra = {}
             if fold:          # RMSNorm folded: W diag(g) (prefill only; the decode GEMVs keep the plain weights)
-                extra["qkv_f"] = d(qkv.float() * W[b + "input_layernorm.weight"].float()[None, :])
+                # rows in the order the fused RoPE epilogue wants (identity for head_dim 64): self.qkv_f_permuted
+                extra["qkv_f"] = d((qkv.float() * W[b + "input_layernorm.weight"].float()[None, :])[qkv_order])
                 extra["gu_f"] = d(gu.float() * W[b + "post_attention_layernorm.weight"].float()[None, :])
             self.layers.append(dict(**extra, ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv),
                                     o=d(W[b + "self_attn.o_proj.weight"]),
@@ -642,7 +649,7 @@ class GARModel:
         L, Hkv, hd = t.num_hidden_layers, t.num_key_value_heads, t.head_dim
         st = dict(
             Kc=self._buf(key, "Kc", (L, B, Hkv, Smax, hd), zero=True),
-            Vtc=self._buf(key, "Vtc", (L, B, Hkv, hd, Smax), zero=True),
+            Vc=self._buf(key, "Vc", (L, B, Hkv, Smax, hd), zero=True),      # row-major like K: an append is one row
             counters=self._buf(key, "counters", (4,), torch.int32, zero=True),   # [pos, kv_len, step, -]
             cur=self._buf(key, "cur", (B,), torch.int64, zero=True),
             # first real row of every sequence (left-padded batch; zeros otherwise): read by the qkv-post and attention
@@ -659,7 +666,6 @@ class GARModel:
         key = ("prefill", B, S)
         h = embeds.view(B * S, C_l)
         xn = None                                      # the normalised copy of h: only without folded norms
-        qkv = self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
         Spad = _round_up(S, 64)
         Q = self._buf(key, "Q", (B, Hq, Spad, hd))
         att = self._buf(key, "att", (B * S, Hq * hd))
@@ -677,15 +683,25 @@ class GARModel:
             ops.row_rstd(h, t.rms_norm_eps, True, rstd)                  # input_layernorm of layer 0: h came from the embedding pass
         else:
             xn = self._buf(key, "xn", (B * S, C_l))
+        fused_qkv = fold and self.LLM_QKV_EPILOGUE and hd in (64, 128)
+        if not fused_qkv and fold and self.qkv_f_permuted:
+            raise hip.GarError("qkv_f is stored in the fused epilogue's row order: LLM_QKV_EPILOGUE has to be set before the "
+                               "model is built")
         for li, ly in enumerate(self.layers):
-            Kc, Vtc = st["Kc"][li][b0:b0 + B], st["Vtc"][li][b0:b0 + B]       # this chunk's rows of the shared cache
-            if fold:
-                ops.gemm(h, ly["qkv_f"], qkv, row_scale=rstd)
+            Kc, Vc = st["Kc"][li][b0:b0 + B], st["Vc"][li][b0:b0 + B]         # this chunk's rows of the shared cache
+            if fused_qkv:
+                if not ops.gemm_qkv_rope_llm(h, ly["qkv_f"], Q, Kc, Vc, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, 0, None,
+                                             q_scale, left_pad=lp, row_scale=rstd):
+                    raise hip.GarError("fused qkv GEMM refused a shape tile_gemm_takes() accepted")
             else:
-                ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
-                ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale, left_pad=lp)
-            ops.attention(Q, Kc, Vtc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp)
+                if fold:
+                    ops.gemm(h, ly["qkv_f"], self._qkv_buf(key, B, S, Hq, Hkv, hd), row_scale=rstd)
+                else:
+                    ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
+                    ops.gemm(xn, ly["qkv"], self._qkv_buf(key, B, S, Hq, Hkv, hd))
+                ops.llm_qkv_post(self._qkv_buf(key, B, S, Hq, Hkv, hd), cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, 0,
+                                 None, q_scale, left_pad=lp)
+            ops.attention(Q, Kc, Vc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp, v_row_major=True)
             if fold:
                 ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h, row_stats=stats)
                 ops.row_stats_finalize(stats, C_l, t.rms_norm_eps, True, rstd)
@@ -700,6 +716,10 @@ class GARModel:
                 ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
                 ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
+
+    def _qkv_buf(self, key, B, S, Hq, Hkv, hd):
+        """the [B*S, (Hq + 2 Hkv) hd] qkv GEMM output of the unfused prefill path (f32 / FOLD_NORMS off): lazily allocated"""
+        return self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
 
     def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None):
         """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed). ``normed``: the
@@ -756,9 +776,9 @@ class GARModel:
                 if split == 1 or li == 0:
                     ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vtc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
+            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
                              left_pad=st["left_pad"])
-            ops.attention_decode(Q, st["Kc"][li], st["Vtc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
+            ops.attention_decode(Q, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
                                  kv_start=st["left_pad"])
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
             if fuse:

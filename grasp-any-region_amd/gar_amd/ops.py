@@ -275,21 +275,69 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     return True
 
 
+def llm_qkv_weight_order(hd: int, Hq: int, Hkv: int) -> torch.Tensor:
+    """Row order of the fused Llama qkv weight that GAR_EPI_QKV_ROPE_LLM expects (include/gar_hip.h): inside every q / k head,
+    64-row strip j holds dims [32j, 32j+32) then [hd/2 + 32j, hd/2 + 32j + 32) — a rotation's two halves share a strip;
+    v heads keep their order. Identity for head_dim 64. ``w[order]`` is the weight to pass."""
+    half = hd // 2
+    per_head = torch.cat([torch.cat([torch.arange(32 * j, 32 * j + 32), torch.arange(half + 32 * j, half + 32 * j + 32)])
+                          for j in range(hd // 64)])
+    qk = (torch.arange(Hq + Hkv)[:, None] * hd + per_head[None, :]).reshape(-1)
+    return torch.cat([qk, torch.arange((Hq + Hkv) * hd, (Hq + 2 * Hkv) * hd)])
+
+
+def gemm_qkv_rope_llm(a, w, Q, Kc, Vc, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None,
+                      row_scale: Optional[torch.Tensor] = None) -> bool:
+    """Llama qkv GEMM with gar_llm_qkv_post fused into its epilogue (GAR_EPI_QKV_ROPE_LLM): ``a`` [B*S, C], ``w`` in
+    :func:`llm_qkv_weight_order`; q goes rotated and scaled to ``Q`` [B, Hq, Spad, hd], k (rotated) and v to rows
+    pos0 .. pos0 + S - 1 of ``Kc`` / ``Vc`` [B, Hkv, Smax, hd]. Returns False when the library does not take this shape /
+    dtype on the fused path (caller keeps gemm + llm_qkv_post with the natural weight order)."""
+    M, Kd = a.shape
+    N = w.shape[0]
+    p = GemmParams()
+    p.A, p.lda = ptr(a), a.stride(0)
+    p.W, p.ldw = ptr(w), w.stride(0)
+    p.C, p.ldc = None, 0
+    p.M, p.N, p.K = M, N, Kd
+    p.epilogue = hip.EPI_QKV_ROPE_LLM
+    p.qkv_q, p.qkv_k, p.qkv_v, p.qkv_sin, p.qkv_cos = ptr(Q), ptr(Kc), ptr(Vc), ptr(sin), ptr(cos)
+    p.qkv_heads, p.qkv_head_dim, p.qkv_tokens, p.qkv_tokens_pad = Hq, hd, S, Spad
+    p.qkv_kv_heads, p.qkv_kv_stride, p.qkv_pos0 = Hkv, Smax, pos0
+    p.qkv_pos_dev, p.qkv_left_pad = ptr(pos_dev), ptr(left_pad)
+    p.qkv_q_scale = q_scale
+    p.row_scale = ptr(row_scale)
+    prof = KERNEL_TIMERS
+    timed = prof is not None and not torch.cuda.is_current_stream_capturing()
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
+    if rc == hip.ERR_UNSUPPORTED:
+        return False
+    check(rc, "gar_gemm(QKV_ROPE_LLM)")
+    if timed:
+        e1.record()
+        prof.append(("gemm_tile_bf16", 2.0 * M * N * Kd, (M * Kd + N * Kd + M * N) * a.element_size(), e0, e1))
+    return True
+
+
 def vit_v_transpose(v, Vt, T, N, H, hd, Npad):
     check(lib().gar_vit_v_transpose(dtype_code(v.dtype), ptr(v), ptr(Vt), T, N, H, hd, Npad, stream()),
           "gar_vit_v_transpose")
 
 
-def llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None):
-    """``left_pad`` int32 [B] (device) or None: first real row of each sequence of a left-padded batch."""
-    check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vtc), B, S,
+def llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None):
+    """``Kc``, ``Vc`` [B, Hkv, Smax, hd]. ``left_pad`` int32 [B] (device) or None: first real row of each sequence of a
+    left-padded batch."""
+    check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vc), B, S,
                                  Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), ptr(left_pad), q_scale, stream()),
           "gar_llm_qkv_post")
 
 
 def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None,
               v_row_major: bool = False, kv_start=None, kv_prefix: int = 0):
-    """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout; bf16, head_dim 64) instead of its transpose.
+    """``v_row_major``: ``Vt`` is V [B, Hkv, kv_stride, hd] (K's layout: the fused qkv GEMMs' v output, the Llama KV cache)
+    instead of its transpose.
     ``kv_start`` int32 [B] (device) or None: first visible kv row per sequence (left-padded batch).
     ``kv_prefix`` = 1 (v_row_major, non-causal): kv row 0 is folded into the softmax's initial state (ViT cls token)."""
     if v_row_major:
@@ -301,8 +349,8 @@ def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, caus
                               kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention")
 
 
-def attention_decode(q, Kc, Vtc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None):
-    check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vtc), ptr(O), B, Hq, Hkv, hd, Smax,
+def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None):
+    check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
                                      ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
           "gar_attention_decode")
 

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 8
+#define GAR_ABI_VERSION 9
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -53,6 +53,19 @@ extern "C" {
                                   /* written to qkv_q / qkv_k [tiles, heads, qkv_tokens_pad, head_dim]; v written   */
                                   /* row-major to C [M, heads*head_dim] (transposed later by gar_vit_v_transpose),  */
                                   /* or head-major to qkv_v when that is set (gar_attention_vrow reads it in place)  */
+#define GAR_EPI_QKV_ROPE_LLM 8    /* HF Llama pre-attention step fused into the qkv GEMM (bf16 tile GEMM only; ABI v9): what   */
+                                  /* gar_llm_qkv_post does to the GEMM's output, done on the fp32 accumulators instead — no  */
+                                  /* [M, (Hq+2Hkv) hd] intermediate. Columns [q heads | k heads | v heads] x head_dim (64 /  */
+                                  /* 128), row m = token m % qkv_tokens of sequence m / qkv_tokens. q, k: half-split RoPE    */
+                                  /* (x[d], x[d + hd/2]) at position pos0 + token - qkv_left_pad[seq] (tables qkv_cos /      */
+                                  /* qkv_sin [max_pos, hd/2] f32), q * qkv_q_scale -> qkv_q [B, qkv_heads, qkv_tokens_pad,   */
+                                  /* hd]; k, v -> rows pos0 + token of the caches qkv_k / qkv_v [B, qkv_kv_heads,            */
+                                  /* qkv_kv_stride, hd]. A wave's 64-column strip must hold a rotation's both halves:        */
+                                  /* within every q / k head the W rows are ordered so that strip j (64 j .. 64 j + 63)      */
+                                  /* holds dims [32 j, 32 j + 32) then [hd/2 + 32 j, hd/2 + 32 j + 32) — the natural order   */
+                                  /* for head_dim 64, [0..31, 64..95, 32..63, 96..127] for head_dim 128; v heads natural.    */
+                                  /* No bias. GAR_ERR_UNSUPPORTED (nothing launched) when the tile GEMM does not take the    */
+                                  /* problem: the caller then runs GAR_EPI_NONE + gar_llm_qkv_post (natural W order).        */
 
 typedef void* gar_stream_t;
 
@@ -94,11 +107,17 @@ typedef struct gar_gemm_params {
      * stream x is linear up to a per-row scale: LN(x) W^T + b = rstd_m * (x W''^T) + b' with W'' = (W diag(gamma)) minus each
      * row's mean (the mean subtraction is absorbed by centring the weight rows), b' = b + W beta; RMSNorm: W'' = W diag(g).
      *   row_scale [M] fp32: C = epilogue(row_scale[m] * (A W^T) + bias) — the CONSUMER (qkv / fc1 / gate-up GEMM reading x
-     *     itself; GAR_EPI_NONE, BIAS, BIAS_GELU, SWIGLU, QKV_ROPE with the compact table);
+     *     itself; GAR_EPI_NONE, BIAS, BIAS_GELU, SWIGLU, QKV_ROPE with the compact table, QKV_ROPE_LLM);
      *   row_stats [M][ceil(N/64)][2] fp32: per row and 64-column strip (sum y, sum y^2) of the bf16-rounded outputs y — the
      *     PRODUCER of x (GAR_EPI_RES, GAR_EPI_BIAS_SCALE_RES); gar_row_stats_finalize turns them into row_scale. */
     const float* row_scale;
     float* row_stats;
+    /* GAR_EPI_QKV_ROPE_LLM only (ABI v9); it also uses qkv_q / qkv_k / qkv_v / qkv_sin / qkv_cos / qkv_heads (= Hq) /
+     * qkv_head_dim / qkv_tokens (= S) / qkv_tokens_pad (= Spad of Q) / qkv_q_scale with the meanings given at the define.
+     * qkv_pos_dev (device int32[1]) overrides qkv_pos0 when not NULL; qkv_left_pad device int32 [B] or NULL. */
+    int32_t qkv_kv_heads, qkv_kv_stride, qkv_pos0;
+    const int32_t* qkv_pos_dev;
+    const int32_t* qkv_left_pad;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -169,12 +188,13 @@ int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T, int N, int H,
 
 /* HF Llama pre-attention step on fused qkv [B*S, (Hq+2Hkv)*hd]: half-split RoPE (cos/sin [max_pos, hd/2] f32,
  * row = absolute position pos0+s), q scale folded, Q [B,Hq,Spad,hd]; K and V appended to the cache at
- * positions pos0..pos0+S-1:  Kc [B,Hkv,Smax,hd], Vtc [B,Hkv,hd,Smax].
+ * positions pos0..pos0+S-1:  Kc and Vc [B,Hkv,Smax,hd] both (ABI v9; through v8 V was kept transposed): an appended token
+ * is one contiguous row of either cache, and the attention kernels transpose V on their LDS reads.
  * If `pos_dev` != NULL the start position is read from device memory (pos_dev[0]) instead of pos0 (graph replay).
  * `left_pad` (device int32 [B] or NULL): a LEFT-PADDED batch as HF generation builds it from `attention_mask`
  * (modeling_gar.py:418-426 forwards it): sequence b's first real token sits at row left_pad[b]; a token keeps its row in
  * the cache and rotates by position (row - left_pad[b]) (HF: position_ids = cumsum(attention_mask) - 1). */
-int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* sin, void* Q, void* Kc, void* Vtc,
+int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* sin, void* Q, void* Kc, void* Vc,
                      int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0, const int32_t* pos_dev,
                      const int32_t* left_pad, float q_scale, gar_stream_t stream);
 
@@ -191,9 +211,9 @@ int gar_attention(int dtype, const void* Q, const void* K, const void* Vt, void*
                   const int32_t* kv_start, gar_stream_t stream);
 /* The same with V row-major, [B,Hkv,kv_stride,hd] like K (what GAR_EPI_QKV_ROPE writes to gar_gemm_params.qkv_v): the PV
  * operand is formed by gfx950's transposing LDS read (ds_read_b64_tr_b16), so timm AttentionRope's v needs no transpose
- * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention). bf16, head_dim 64 /
- * 96 / 128;
- * GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
+ * pass between the qkv GEMM and the attention (modeling_perception_lm.py:210-214 -> timm Eva attention), and the Llama KV
+ * cache (gar_llm_qkv_post) keeps V in K's layout. bf16: head_dim 64 / 96 / 128; f32 (parity mode): head_dim 64 / 128, the
+ * tile is transposed while it is staged; GAR_ERR_UNSUPPORTED (nothing launched) otherwise.
  * kv_prefix = 1 (non-causal only): key / value row 0 — the ViT's cls token — enters through the initial softmax state
  * (m0 = q.k0, l0 = 1, O0 = v0) and the kv tiles cover rows 1 .. kv_len - 1: 1 + 1024 keys are 16 tiles, not 17. Same
  * result up to the fp32 summation order. */
@@ -202,13 +222,14 @@ int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, v
                        const int32_t* kv_start, int kv_prefix, gar_stream_t stream);
 
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
- * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / Vt.
- * q [B,Hq,hd] pre-scaled; kv length = kv_len_dev[0] (device memory, so one captured hipGraph replays for every
- * token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes. GAR_F32 routes to gar_attention.
+ * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / V.
+ * q [B,Hq,hd] pre-scaled; Kc, Vc [B,Hkv,Smax,hd] (gar_llm_qkv_post's caches); kv length = kv_len_dev[0] (device memory, so
+ * one captured hipGraph replays for every token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes.
+ * GAR_F32 routes to gar_attention_vrow. bf16: head_dim 64 / 128, Smax * hd * 2 < 2 GiB (GAR_ERR_UNSUPPORTED otherwise).
  * `kv_start` (device int32 [B] or NULL): sequence b's keys are cache rows kv_start[b] .. kv_len - 1 (left-padded batch);
  * the kv splits divide that range. */
 int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits);
-int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vtc, void* O, int B, int Hq, int Hkv,
+int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq, int Hkv,
                          int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits,
                          void* workspace, gar_stream_t stream);
 

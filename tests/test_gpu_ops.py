@@ -450,19 +450,42 @@ def test_attention_lazy_max_redo_path(dev, hd, causal, profile):
             close(out3, ref3, dt, extra=2.0)
 
 
-def test_attention_vrow_refuses_f32(dev):
+def test_attention_vrow_refuses_what_is_not_built(dev):
+    """f32 row-major V: head_dim 64 / 128 only, no kv_prefix (the parity path has no cls-key fold); nothing launched."""
     from gar_amd import hip, ops
+    Q = torch.zeros(1, 1, 64, 96, dtype=torch.float32, device=dev)
+    with pytest.raises(hip.GarError):
+        ops.attention(Q, Q, Q, torch.zeros(64, 96, dtype=torch.float32, device=dev), 1, 1, 1, 96, 64, 64, 64, 64,
+                      causal=False, v_row_major=True)
     Q = torch.zeros(1, 1, 64, 64, dtype=torch.float32, device=dev)
     with pytest.raises(hip.GarError):
         ops.attention(Q, Q, Q, torch.zeros(64, 64, dtype=torch.float32, device=dev), 1, 1, 1, 64, 64, 64, 64, 64,
-                      causal=False, v_row_major=True)
+                      causal=False, v_row_major=True, kv_prefix=1)
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_f32_row_major_v_equals_transposed(dev, hd, causal):
+    """parity mode: the f32 kernel stages a row-major V tile transposed — same arithmetic, bit-identical output."""
+    from gar_amd import ops
+    B, Hq, Hkv, n = 2, 4, 2, 150
+    npad = 192
+    Q = (rnd(B, Hq, npad, hd, seed=5) * 0.2).to(dev)
+    K = rnd(B, Hkv, npad, hd, seed=6).to(dev)
+    Vt = rnd(B, Hkv, hd, npad, seed=7).to(dev)
+    Vr = Vt.transpose(2, 3).contiguous()
+    a = torch.empty(B * n, Hq * hd, device=dev)
+    b = torch.empty_like(a)
+    ops.attention(Q, K, Vt, a, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
+    ops.attention(Q, K, Vr, b, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal, v_row_major=True)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("S", [70, 333, 129])
 def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
-    """llm_qkv_post (half-split RoPE, GQA, cache append incl. transposed V) + causal prefill attention, then two
+    """llm_qkv_post (half-split RoPE, GQA, append to the row-major K / V caches) + causal prefill attention, then two
     single-token decode steps with the kv length read from device memory."""
     from gar_amd import ops
     from oracle import gar_oracle as O
@@ -474,7 +497,7 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     fr = pos[:, None] * inv[None]
     cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
     Kc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
-    Vtc = torch.zeros(B, Hkv, hd, Smax, dtype=dt, device=dev)
+    Vc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
     scale = (hd ** -0.5) * 1.4426950408889634
 
     def ref_qkv(x, p0):
@@ -490,15 +513,15 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     Spad = (S + 63) // 64 * 64
     Q = torch.empty(B, Hq, Spad, hd, dtype=dt, device=dev)
     out = torch.empty(B * S, Hq * hd, dtype=dt, device=dev)
-    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax,
+    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax,
                      0, None, scale)
-    ops.attention(Q, Kc, Vtc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True)
+    ops.attention(Q, Kc, Vc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, v_row_major=True)
     rq, rk, rv = ref_qkv(qkv, 0)
     rep = Hq // Hkv
     ref = _attn_ref(rq, rk.repeat_interleave(rep, 1), rv.repeat_interleave(rep, 1), True, 0)
     close(out, ref.transpose(1, 2).reshape(B * S, Hq * hd), dt, extra=2.0)
     close(Kc[:, :, :S], rk, dt)
-    close(Vtc[:, :, :, :S], rv.transpose(-1, -2), dt)
+    close(Vc[:, :, :S], rv, dt)
     # decode
     counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
     Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
@@ -506,14 +529,14 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     ks, vs = [rk], [rv]
     for step in range(2):
         x1 = q(rnd(B, 1, Wd, seed=23 + step), dt)
-        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vtc, B, 1, 1, Hq, Hkv, hd, Smax,
+        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vc, B, 1, 1, Hq, Hkv, hd, Smax,
                          0, counters[0:1], scale)
-        ops.attention(Q1, Kc, Vtc, o1, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False, kv_len_dev=counters[1:2])
+        ops.attention(Q1, Kc, Vc, o1, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False, kv_len_dev=counters[1:2], v_row_major=True)
         o2s = []
         for nsplit in (1, 3, 16):       # split-KV decode kernel (bf16) / routed to the same f32 kernel in parity mode
             ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, nsplit), dtype=torch.uint8, device=dev)
             o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
-            ops.attention_decode(Q1, Kc, Vtc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws)
+            ops.attention_decode(Q1, Kc, Vc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws)
             o2s.append(o2)
         ops.counter_add(counters, 1)
         q1, k1, v1 = ref_qkv(x1, S + step)
@@ -560,13 +583,13 @@ def test_llm_left_padded_batch_attention(dev, dt, hd):
     qkv = q(rnd(B, S, Wd, seed=41), dt)
     Spad = (S + 63) // 64 * 64
     Kc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
-    Vtc = torch.zeros(B, Hkv, hd, Smax, dtype=dt, device=dev)
+    Vc = torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev)
     Q = torch.empty(B, Hq, Spad, hd, dtype=dt, device=dev)
     out = torch.full((B * S, Hq * hd), float("nan"), dtype=dt, device=dev)
     lp = torch.tensor(pads, dtype=torch.int32, device=dev)
-    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax,
+    ops.llm_qkv_post(qkv.view(B * S, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax,
                      0, None, scale, left_pad=lp)
-    ops.attention(Q, Kc, Vtc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp)
+    ops.attention(Q, Kc, Vc, out, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp, v_row_major=True)
     assert torch.isfinite(out.float()).all()               # padding rows too: they flow through the following GEMMs
     outv = out.view(B, S, Hq * hd)
     refs = []
@@ -575,18 +598,19 @@ def test_llm_left_padded_batch_attention(dev, dt, hd):
         ref = _attn_ref(rq, rk.repeat_interleave(rep, 1), rv.repeat_interleave(rep, 1), True, 0)
         close(outv[b, pd:], ref.transpose(1, 2).reshape(S - pd, Hq * hd), dt, extra=2.0)
         close(Kc[b, :, pd:S], rk[0], dt)
+        close(Vc[b, :, pd:S], rv[0], dt)
         refs.append(([rk], [rv]))
     counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
     Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
     for step in range(2):
         x1 = q(rnd(B, 1, Wd, seed=43 + step), dt)
-        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vtc, B, 1, 1, Hq, Hkv, hd, Smax,
+        ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vc, B, 1, 1, Hq, Hkv, hd, Smax,
                          0, counters[0:1], scale, left_pad=lp)
         outs = []
         for nsplit in (1, 3, 16):
             ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, nsplit), dtype=torch.uint8, device=dev)
             o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
-            ops.attention_decode(Q1, Kc, Vtc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws, kv_start=lp)
+            ops.attention_decode(Q1, Kc, Vc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws, kv_start=lp)
             outs.append(o2)
         ops.counter_add(counters, 1)
         for b, pd in enumerate(pads):
@@ -1077,6 +1101,105 @@ def test_fused_qkv_rope_with_folded_layernorm(dev):
     close(Q1[:, :, :N], (rope(qr) * qs).permute(0, 2, 1, 3), dt, extra=1.5)
     close(K1[:, :, :N], rope(kr).permute(0, 2, 1, 3), dt, extra=1.5)
     close(V1[:, :, :N], vr.permute(0, 2, 1, 3), dt, extra=1.5)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,B,S", [(64, 8, 2, 3, 3700), (128, 4, 2, 3, 2800), (64, 8, 2, 130, 90)])
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("padded", [False, True])
+def test_fused_llm_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, hd, Hq, Hkv, B, S, fold, padded):
+    """GAR_EPI_QKV_ROPE_LLM (half-split RoPE, q scale and the KV-cache append in the qkv GEMM's epilogue; W rows in
+    llm_qkv_weight_order) against the two-kernel path (GAR_EPI_NONE GEMM -> gar_llm_qkv_post, natural W order) and against an
+    fp64 statement of HF's apply_rotary_pos_emb; the fused path rounds to bf16 once instead of twice. With a left-padded
+    batch (RoPE position = row - left_pad), a start position > 0, a folded RMSNorm (row_scale), and sequences shorter than a
+    wave's 128-row strip (S = 90: the per-row division path)."""
+    from gar_amd import ops
+    from oracle import gar_oracle as O
+    dt = torch.bfloat16
+    Kd = 256
+    Wd = (Hq + 2 * Hkv) * hd
+    p0 = 5
+    Smax = (p0 + S + 63) // 64 * 64
+    Spad = (S + 63) // 64 * 64
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = pos[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    qs = hd ** -0.5 * 1.4426950408889634
+    a = q(rnd(B * S, Kd, seed=120) * 1.2, dt)
+    W = q(rnd(Wd, Kd, seed=121, scale=Kd ** -0.5), dt)
+    ad, Wn = a.to(dev, dt), W.to(dev, dt)
+    Wp = W[ops.llm_qkv_weight_order(hd, Hq, Hkv)].contiguous().to(dev, dt)
+    pads = [(7 * b) % max(S - 1, 1) for b in range(B)] if padded else None
+    lp = torch.tensor(pads, dtype=torch.int32, device=dev) if padded else None
+    rstd = None
+    if fold:
+        rstd = torch.empty(B * S, dtype=torch.float32, device=dev)
+        ops.row_rstd(ad, 1e-5, True, rstd)
+    Q1 = torch.zeros(B, Hq, Spad, hd, dtype=dt, device=dev)
+    K1, V1 = (torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev) for _ in range(2))
+    assert ops.gemm_qkv_rope_llm(ad, Wp, Q1, K1, V1, cos.to(dev), sin.to(dev), B, S, Spad, Hq, Hkv, hd, Smax, p0, None, qs,
+                                 left_pad=lp, row_scale=rstd)
+    # two-kernel path
+    qkv = torch.empty(B * S, Wd, dtype=dt, device=dev)
+    ops.gemm(ad, Wn, qkv, row_scale=rstd)
+    Q2 = torch.zeros_like(Q1)
+    K2, V2 = torch.zeros_like(K1), torch.zeros_like(V1)
+    ops.llm_qkv_post(qkv, cos.to(dev), sin.to(dev), Q2, K2, V2, B, S, Spad, Hq, Hkv, hd, Smax, p0, None, qs, left_pad=lp)
+    close(Q1, Q2, dt, extra=2.0)
+    close(K1, K2, dt, extra=2.0)
+    close(V1, V2, dt, extra=2.0)
+    assert float(K1[:, :, :p0].float().abs().max()) == 0.0 and float(K1[:, :, p0 + S:].float().abs().max()) == 0.0
+    assert float(V1[:, :, :p0].float().abs().max()) == 0.0 and float(Q1[:, :, S:].float().abs().max()) == 0.0
+    # fp64 statement
+    x = a.double() @ W.double().T
+    if fold:
+        x = x * (a.double().pow(2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    x = x.view(B, S, Wd)
+    xq = x[..., :Hq * hd].view(B, S, Hq, hd).transpose(1, 2)
+    xk = x[..., Hq * hd:(Hq + Hkv) * hd].view(B, S, Hkv, hd).transpose(1, 2)
+    xv = x[..., (Hq + Hkv) * hd:].view(B, S, Hkv, hd).transpose(1, 2)
+    rp = torch.stack([(p0 + torch.arange(S) - (pads[b] if padded else 0)).clamp(min=0) for b in range(B)])     # [B, S]
+    c = torch.cat([cos, cos], -1).double()[rp][:, None]
+    s_ = torch.cat([sin, sin], -1).double()[rp][:, None]
+    rq = (xq * c + O._rotate_half(xq) * s_) * qs
+    rk = xk * c + O._rotate_half(xk) * s_
+    close(Q1[:, :, :S], rq, dt, extra=1.5)
+    close(K1[:, :, p0:p0 + S], rk, dt, extra=1.5)
+    close(V1[:, :, p0:p0 + S], xv, dt, extra=1.5)
+
+
+def test_fused_llm_qkv_rope_start_position_from_device_memory(dev):
+    """qkv_pos_dev overrides qkv_pos0 (graph replay convention of gar_llm_qkv_post)."""
+    from gar_amd import ops
+    dt = torch.bfloat16
+    hd, Hq, Hkv, B, S, Kd = 64, 8, 2, 3, 3700, 128
+    Smax, Spad = 3840, 3712
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = (pos[:, None] * inv[None]).to(dev)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    a = q(rnd(B * S, Kd, seed=130), dt).to(dev, dt)
+    W = q(rnd((Hq + 2 * Hkv) * hd, Kd, seed=131, scale=Kd ** -0.5), dt).to(dev, dt)
+    outs = []
+    for dev_pos in (False, True):
+        Q1 = torch.zeros(B, Hq, Spad, hd, dtype=dt, device=dev)
+        K1, V1 = (torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev) for _ in range(2))
+        pd = torch.tensor([9], dtype=torch.int32, device=dev) if dev_pos else None
+        assert ops.gemm_qkv_rope_llm(a, W, Q1, K1, V1, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, 0 if dev_pos else 9, pd, 0.18)
+        outs.append((Q1, K1, V1))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+def test_fused_llm_qkv_rope_refuses_small_problems(dev):
+    """below the tile GEMM's size the fused epilogue does not exist: False (nothing launched), the caller keeps two kernels."""
+    from gar_amd import ops
+    dt = torch.bfloat16
+    hd, Hq, Hkv, B, S, Kd = 64, 4, 2, 2, 100, 128
+    z = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)
+    t = torch.zeros(128, hd // 2, device=dev)
+    assert not ops.gemm_qkv_rope_llm(z(B * S, Kd), z((Hq + 2 * Hkv) * hd, Kd), z(B, Hq, 128, hd), z(B, Hkv, 128, hd),
+                                     z(B, Hkv, 128, hd), t, t, B, S, 128, Hq, Hkv, hd, 128, 0, None, 0.18)
 
 
 def test_abi_errors_are_reported_not_thrown(dev):

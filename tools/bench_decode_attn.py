@@ -18,7 +18,7 @@ def main():
     L = 4                                   # distinct caches so the stream comes from HBM
     for B in (16, 64):
         Kc = [torch.randn(B, Hkv, Smax, hd, device=dev).to(dt) for _ in range(L)]
-        Vt = [torch.randn(B, Hkv, hd, Smax, device=dev).to(dt) for _ in range(L)]
+        Vc = [torch.randn(B, Hkv, Smax, hd, device=dev).to(dt) for _ in range(L)]       # same bytes in either V layout
         q = torch.randn(B, Hq, hd, device=dev).to(dt)
         O = torch.empty(B, Hq * hd, device=dev, dtype=dt)
         kvl = torch.tensor([kv], dtype=torch.int32, device=dev)
@@ -27,7 +27,7 @@ def main():
 
             def run():
                 for i in range(L):
-                    ops.attention_decode(q, Kc[i], Vt[i], O, B, Hq, Hkv, hd, Smax, kvl, ns, ws)
+                    ops.attention_decode(q, Kc[i], Vc[i], O, B, Hq, Hkv, hd, Smax, kvl, ns, ws)
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

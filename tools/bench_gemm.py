@@ -24,6 +24,7 @@ SHAPES = [("vit qkv", 139400, 3072, 1024, hip.EPI_BIAS), ("vit proj", 139400, 10
 # the planner's passes (gar_amd/planner.py, bench default): 387 image tiles x 1025 tokens, 26 sequences x 4718 tokens
 PLAN_SHAPES = [("vit qkv rope", 396675, 3072, 1024, hip.EPI_QKV_ROPE), ("vit qkv", 396675, 3072, 1024, hip.EPI_BIAS), ("vit proj", 396675, 1024, 1024, hip.EPI_BIAS_SCALE_RES),
                ("vit fc1", 396675, 4096, 1024, hip.EPI_BIAS_GELU), ("vit fc2", 396675, 1024, 4096, hip.EPI_BIAS_SCALE_RES),
+               ("llm qkv rope", 122668, 3072, 2048, hip.EPI_QKV_ROPE_LLM),
                ("llm qkv", 122668, 3072, 2048, hip.EPI_NONE), ("llm o", 122668, 2048, 2048, hip.EPI_RES),
                ("llm gate/up", 122668, 16384, 2048, hip.EPI_SWIGLU), ("llm down", 122668, 2048, 8192, hip.EPI_RES)]
 
@@ -45,10 +46,10 @@ def main():
         kw = {}
         fold = os.environ.get("FOLD") == "1"          # folded norms: row_scale on the consumers, row_stats on the producers
         rs = torch.rand(M, device=dev) + 0.5 if fold and epi in (hip.EPI_NONE, hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_SWIGLU,
-                                                                    hip.EPI_QKV_ROPE) else None
+                                                                    hip.EPI_QKV_ROPE, hip.EPI_QKV_ROPE_LLM) else None
         if fold and epi in (hip.EPI_RES, hip.EPI_BIAS_SCALE_RES):
             kw["row_stats"] = torch.empty(M, (N + 63) // 64, 2, device=dev, dtype=torch.float32)
-        if rs is not None and epi != hip.EPI_QKV_ROPE:
+        if rs is not None and epi not in (hip.EPI_QKV_ROPE, hip.EPI_QKV_ROPE_LLM):
             kw["row_scale"] = rs
         if epi in (hip.EPI_BIAS, hip.EPI_BIAS_GELU, hip.EPI_BIAS_SCALE_RES, hip.EPI_QKV_ROPE):
             kw["bias"] = torch.randn(N, device=dev).to(torch.bfloat16)
@@ -64,6 +65,16 @@ def main():
 
             def call():
                 assert ops.gemm_qkv_rope(a, w, kw["bias"], out, Q_, K_, sin, cos, H, hd, 1025, 1088, 1, 0.18, V=V_, row_scale=rs)
+        elif epi == hip.EPI_QKV_ROPE_LLM:   # the fused Llama prefill qkv GEMM: 32 q / 8 kv heads x 64, 26 sequences of 4718 tokens
+            Hq, Hkv, hd, S = 32, 8, 64, 4718
+            B_ = M // S
+            Q_ = torch.zeros(B_, Hq, 4736, hd, device=dev, dtype=torch.bfloat16)
+            K_, V_ = (torch.zeros(B_, Hkv, 4864, hd, device=dev, dtype=torch.bfloat16) for _ in range(2))
+            ang = torch.randn(4864, hd // 2, device=dev)
+            cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+
+            def call():
+                assert ops.gemm_qkv_rope_llm(a, w, Q_, K_, V_, cos, sin, B_, S, 4736, Hq, Hkv, hd, 4864, 0, None, 0.18, row_scale=rs)
         else:
             def call():
                 ops.gemm(a, w, out, epi, **kw)

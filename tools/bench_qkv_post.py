@@ -22,10 +22,10 @@ def main():
     sin = torch.randn(Smax, hd // 2, device=dev)
     Q = torch.empty(B, Hq, Spad, hd, device=dev, dtype=dt)
     Kc = torch.zeros(B, Hkv, Smax, hd, device=dev, dtype=dt)
-    Vtc = torch.zeros(B, Hkv, hd, Smax, device=dev, dtype=dt)
+    Vc = torch.zeros(B, Hkv, Smax, hd, device=dev, dtype=dt)
 
     def run():
-        ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vtc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, 0.18)
+        ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, 0.18)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
