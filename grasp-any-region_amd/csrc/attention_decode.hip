@@ -38,6 +38,10 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p, int row4_bytes) {
 // fragments into registers, immediately re-arm the region with the DMA of the wave's next tile, then compute on the
 // registers — no block-level barrier in the loop.
 // 64 KiB + merge buffer per block -> two blocks (8 waves) per CU, 128 KiB of loads in flight per CU.
+#ifndef DA_KV_AUX               /* cache policy of the K / V DMA: 2 = nt — every byte of the cache is read once per step:
+                                   B = 64, kv 4750: 105.8 -> 98.2 us (5.88 -> 6.34 TB/s; profiles/r3_decode_nt.txt) */
+#define DA_KV_AUX 2
+#endif
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
 __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, float* __restrict__ part,
@@ -79,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + i * 1024), 16,
-                                                     offK[i & 1] + (int)(base + (unsigned)i * 1024u), 0, 0, 0);
+                                                     offK[i & 1] + (int)(base + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + i * 1024), 16,
-                                                     offV + (int)(base + (unsigned)i * 1024u), 0, 0, 0);
+                                                     offV + (int)(base + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
     };
     bf16x8 qf[NKD];
     {
@@ -276,14 +280,14 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + i * 1024), 16,
-                                                     offK[i & 3] + (int)(kbase + (unsigned)i * 1024u), 0, 0, 0);
+                                                     offK[i & 3] + (int)(kbase + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
     };
     auto stageV = [&](int t) {
         const unsigned vbase = (unsigned)t * 64u * 256u;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + i * 1024), 16,
-                                                     offV + (int)(vbase + (unsigned)i * 1024u), 0, 0, 0);
+                                                     offV + (int)(vbase + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
     };
     bf16x8 qf[NKD];
     {

@@ -16,6 +16,11 @@
 #ifndef SKINNY_WD_NARROW        /* weight-ring depth of the staged path for NT <= 2 (1 = re-arm one step at a time) */
 #define SKINNY_WD_NARROW 4
 #endif
+#ifndef SK_W_AUX                /* cache policy of the weight DMA: 2 = nt. A decode step streams each weight byte once (2.47 GB per
+                                   token against 4 MiB of L2 per XCD and a 256 MB Infinity Cache): gate/up -7 %, lm_head -2.5 %,
+                                   qkv / o -3 % against the default policy (COLD=1 tools/bench_skinny.py, profiles/r3_decode_nt.txt) */
+#define SK_W_AUX 2
+#endif
 #define SKINNY_WD(NT_) ((NT_) <= 2 ? SKINNY_WD_NARROW : 1)
 
 // STAGED: every wave brings the [16 x 64] bf16 tiles of a K step (NT weight tiles + MT activation tiles, 2 KiB each)
@@ -93,7 +98,7 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(slot + t * 2048 + i * 1024), 16,
-                                                         voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, 0);
+                                                         voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, SK_W_AUX);
     };
     auto stage_x = [&](int ks) {
         const unsigned k0b = (unsigned)ks * 128u;
