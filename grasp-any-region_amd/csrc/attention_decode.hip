@@ -38,6 +38,75 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p, int row4_bytes) {
 // fragments into registers, immediately re-arm the region with the DMA of the wave's next tile, then compute on the
 // registers — no block-level barrier in the loop.
 // 64 KiB + merge buffer per block -> two blocks (8 waves) per CU, 128 KiB of loads in flight per CU.
+// ---- gar_llm_qkv_post (S = 1) fused into the attention launch (gar_attention_decode_qkv) ------------------------------
+// The step's raw qkv GEMM output [B, (Hq + 2 Hkv) HD] replaces Q: every block rotates and scales its G query heads while it
+// loads them (a lane's MFMA fragments hold dims 16 kd + 8 h + e for all kd: both halves of every rotation pair), and the
+// wave that owns the LAST kv tile rotates the new key, appends key and value to the caches (global rows `pos`) and patches
+// them into its LDS tiles after the DMA of that tile has landed — the DMA may or may not have seen the global rows.
+struct decode_qkv_args {
+    const bf16_t* raw;          // NULL: plain gar_attention_decode (Q, caches already appended)
+    const float* cs;
+    const float* sn;            // [max_pos, HD / 2] f32
+    float q_scale;
+};
+
+template <int HD>
+__device__ __forceinline__ void load_q_rotated(bf16x8 (&qf)[HD / 16], const decode_qkv_args& fa, int b, int Hq, int Hkv, int head,
+                                               bool valid, int h, int rp) {
+    constexpr int HALF = HD / 2, NKD = HD / 16;
+    const bf16_t* rq = fa.raw + ((int64_t)b * (Hq + 2 * Hkv) + head) * HD;
+#pragma unroll
+    for (int kd = 0; kd < NKD / 2; ++kd) {
+        const int off = kd * 16 + h * 8;
+        float x1[8], x2[8], c[8], sv[8];
+        ld8(rq + off, x1);
+        ld8(rq + HALF + off, x2);
+        ld8(fa.cs + (int64_t)rp * HALF + off, c);
+        ld8(fa.sn + (int64_t)rp * HALF + off, sv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rope_half_pair(x1[e], x2[e], c[e], sv[e], fa.q_scale, x1[e], x2[e]);
+        const u32x4 w1 = {pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]), pack_bf2(x1[4], x1[5]), pack_bf2(x1[6], x1[7])};
+        const u32x4 w2 = {pack_bf2(x2[0], x2[1]), pack_bf2(x2[2], x2[3]), pack_bf2(x2[4], x2[5]), pack_bf2(x2[6], x2[7])};
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        qf[kd] = __builtin_bit_cast(bf16x8, valid ? w1 : z);
+        qf[kd + NKD / 2] = __builtin_bit_cast(bf16x8, valid ? w2 : z);
+    }
+}
+
+// new key (rotated) and value row of (b, kvh) at cache row `pos`: global append + patch of the wave's LDS tiles (row pos & 63).
+// KEYFN / VKEYFN: chunk swizzle of a K / V tile row (the kernels' DMA layouts). Lanes 0 .. HD/16-1 do the key (8 dims of each
+// half), lanes 0 .. HD/8-1 the value.
+template <int HD, bool DO_K, bool DO_V, typename KF, typename VF>
+__device__ __forceinline__ void append_new_kv(const decode_qkv_args& fa, bf16_t* Kp, bf16_t* Vp, char* ks, char* vs, int b, int Hq,
+                                              int Hkv, int kvh, int lane, int pos, int rp, KF kkey, VF vkey) {
+    constexpr int HALF = HD / 2, RB = HD * 2;
+    const int r = pos & 63;
+    const bf16_t* row = fa.raw + (int64_t)b * (Hq + 2 * Hkv) * HD;
+    if (DO_K && lane < HALF / 8) {
+        const int i8 = lane * 8;
+        const bf16_t* rk = row + (Hq + kvh) * HD;
+        float x1[8], x2[8], c[8], sv[8];
+        ld8(rk + i8, x1);
+        ld8(rk + HALF + i8, x2);
+        ld8(fa.cs + (int64_t)rp * HALF + i8, c);
+        ld8(fa.sn + (int64_t)rp * HALF + i8, sv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rope_half_pair(x1[e], x2[e], c[e], sv[e], 1.0f, x1[e], x2[e]);
+        const uint4 w1 = make_uint4(pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3]), pack_bf2(x1[4], x1[5]), pack_bf2(x1[6], x1[7]));
+        const uint4 w2 = make_uint4(pack_bf2(x2[0], x2[1]), pack_bf2(x2[2], x2[3]), pack_bf2(x2[4], x2[5]), pack_bf2(x2[6], x2[7]));
+        *reinterpret_cast<uint4*>(Kp + (int64_t)pos * HD + i8) = w1;
+        *reinterpret_cast<uint4*>(Kp + (int64_t)pos * HD + HALF + i8) = w2;
+        *reinterpret_cast<uint4*>(ks + r * RB + ((lane ^ kkey(r)) << 4)) = w1;
+        *reinterpret_cast<uint4*>(ks + r * RB + (((lane + HALF / 8) ^ kkey(r)) << 4)) = w2;
+    }
+    if (DO_V && lane < HD / 8) {
+        const uint4 w = *reinterpret_cast<const uint4*>(row + (Hq + Hkv + kvh) * HD + lane * 8);
+        *reinterpret_cast<uint4*>(Vp + (int64_t)pos * HD + lane * 8) = w;
+        *reinterpret_cast<uint4*>(vs + r * RB + ((lane ^ vkey(r)) << 4)) = w;
+    }
+    asm volatile("" ::: "memory");          // the fragment reads that follow (ds_read / transposing reads) stay behind the patch
+}
+
 #ifndef DA_KV_AUX               /* cache policy of the K / V DMA: 2 = nt — every byte of the cache is read once per step:
                                    B = 64, kv 4750: 105.8 -> 98.2 us (5.88 -> 6.34 TB/s; profiles/r3_decode_nt.txt) */
 #define DA_KV_AUX 2
@@ -47,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ V, float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
                                                                  const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
-                                                                 bf16_t* __restrict__ O_direct) {
+                                                                 bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
     constexpr int HD = 64, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | V 8 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 16384);
-    const int kv_len = kv_len_dev[0];
+    const int kv_len = kv_len_dev[0] + (fa.raw ? 1 : 0);            // fused: kv_len_dev is the step's position, the new row included
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -90,7 +159,10 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
                                                      offV + (int)(base + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
     };
     bf16x8 qf[NKD];
-    {
+    const int rp = max(kv_len - 1 - (kv_start ? kv_start[b] : 0), 0);         // fused: RoPE position of the step's token
+    if (fa.raw) {
+        load_q_rotated<HD>(qf, fa, b, Hq, Hkv, kvh * G + min(l31, G - 1), l31 < G, h, rp);
+    } else {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
 #pragma unroll
@@ -124,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     if (t < t1) stage(t);
     for (; t < t1; t += 4) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fa.raw && t == ntiles - 1)           // the tile that holds the step's own row: this wave appends it
+            append_new_kv<HD, true, true>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+                                          kv_len - 1, rp, [](int r) { return (r >> 1) & 7; }, [](int r) { return ((r >> 1) & 1) << 2; });
         bf16x8 kf[2][NKD], vf[NDB][4];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -241,11 +316,11 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ V, float* __restrict__ part,
                                                                     int Hq, int Hkv, int kv_stride,
                                                                     const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
-                                                                    bf16_t* __restrict__ O_direct) {
+                                                                    bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
     constexpr int HD = 128, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | V 16 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 32768);
-    const int kv_len = kv_len_dev[0];
+    const int kv_len = kv_len_dev[0] + (fa.raw ? 1 : 0);            // fused: kv_len_dev is the step's position, the new row included
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -290,7 +365,10 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                                                      offV + (int)(vbase + (unsigned)i * 1024u), 0, 0, DA_KV_AUX);
     };
     bf16x8 qf[NKD];
-    {
+    const int rp = max(kv_len - 1 - (kv_start ? kv_start[b] : 0), 0);         // fused: RoPE position of the step's token
+    if (fa.raw) {
+        load_q_rotated<HD>(qf, fa, b, Hq, Hkv, kvh * G + min(l31, G - 1), l31 < G, h, rp);
+    } else {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
 #pragma unroll
@@ -323,6 +401,10 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
     for (; t < t1; t += 4) {
         const bool more = t + 4 < t1;
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K(t) landed; the 16 V(t) pieces may still be out
+        const bool own_new = fa.raw && t == ntiles - 1;            // the tile that holds the step's own row (this wave's last tile)
+        if (own_new)
+            append_new_kv<HD, true, false>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+                                           kv_len - 1, rp, [](int r) { return r & 15; }, [](int r) { return (r & 3) << 2; });
         f32x16 s[2];
         {
             bf16x8 kf[2][NKD];
@@ -382,6 +464,9 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
         // V(t): everything issued before K(t+4) has to be in; the 16 K pieces just issued may stay out
         if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (own_new)                            // (the key row's global stores sit behind vmcnt(0) too: `more` is false here)
+            append_new_kv<HD, false, true>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+                                           kv_len - 1, rp, [](int r) { return r & 15; }, [](int r) { return (r & 3) << 2; });
         bf16x8 vf[NDB][4];
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
@@ -471,16 +556,9 @@ extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max
     return (int64_t)B * Hq * max_splits * (hd + 2) * 4;
 }
 
-extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq,
-                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
-                                    int max_splits, void* workspace, gar_stream_t stream) {
-    GAR_CHECK_ARG(q && Kc && Vc && O && kv_len_dev, "attention_decode: null pointer");
-    GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
-    GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
-    GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
-    if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
-        return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, 0, stream);
-    GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
+static int launch_decode(const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq, int Hkv, int hd, int Smax,
+                         const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits, void* workspace,
+                         const decode_qkv_args& fa, gar_stream_t stream) {
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
     if ((int64_t)Smax * hd * 2 >= ((int64_t)1 << 31)) {       // one (sequence, kv head) slab has to fit a buffer descriptor
         gar_set_error("attention_decode: Smax %d x head_dim %d exceeds the 2 GiB per-slab range of the DMA-staged kernels", Smax, hd);
@@ -498,7 +576,7 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
         hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
+                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
@@ -510,11 +588,44 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
         hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct);
+                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     }
     GAR_CHECK_LAUNCH();
     return GAR_OK;
+}
+
+extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq,
+                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
+                                    int max_splits, void* workspace, gar_stream_t stream) {
+    GAR_CHECK_ARG(q && Kc && Vc && O && kv_len_dev, "attention_decode: null pointer");
+    GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
+    GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
+    GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
+    if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
+        return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, 0, stream);
+    GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
+    const decode_qkv_args none = {nullptr, nullptr, nullptr, 0.f};
+    return launch_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, kv_start, max_splits, workspace, none, stream);
+}
+
+// gar_llm_qkv_post (S = 1) + gar_attention_decode in ONE launch (bf16): see decode_qkv_args. GAR_ERR_UNSUPPORTED (nothing
+// launched) in parity mode: the caller keeps the two calls.
+extern "C" int gar_attention_decode_qkv(int dtype, const void* qkv, const float* cos, const float* sin, void* Kc, void* Vc,
+                                        void* O, int B, int Hq, int Hkv, int hd, int Smax, const int32_t* pos_dev,
+                                        const int32_t* left_pad, float q_scale, int max_splits, void* workspace,
+                                        gar_stream_t stream) {
+    GAR_CHECK_ARG(qkv && cos && sin && Kc && Vc && O && pos_dev, "attention_decode_qkv: null pointer");
+    GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode_qkv: Hq/Hkv must be <= 8");
+    GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode_qkv: Smax must be a multiple of 64");
+    GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode_qkv: head_dim %d not built (64, 128)", hd);
+    GAR_CHECK_ARG(((uintptr_t)qkv & 15) == 0, "attention_decode_qkv: qkv must be 16-byte aligned");
+    if (dtype != GAR_BF16) {
+        gar_set_error("attention_decode_qkv: bf16 only (parity mode runs gar_llm_qkv_post + gar_attention_decode)");
+        return GAR_ERR_UNSUPPORTED;
+    }
+    const decode_qkv_args fa = {(const bf16_t*)qkv, cos, sin, q_scale};
+    return launch_decode(nullptr, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev, left_pad, max_splits, workspace, fa, stream);
 }

@@ -83,6 +83,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// HF Llama apply_rotary_pos_emb on one (x[d], x[d + hd/2]) pair: q*cos + rotate_half(q)*sin, then the scale folded into q.
+// One explicit operation order, shared by gar_llm_qkv_post and the decode attention's fused prologue: the two paths are
+// bit-identical.
+__device__ __forceinline__ void rope_half_pair(float x1, float x2, float c, float s, float sc, float& o1, float& o2) {
+    o1 = __builtin_fmaf(-x2, s, x1 * c) * sc;
+    o2 = __builtin_fmaf(x1, s, x2 * c) * sc;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf via Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7) without the 1+erf cancellation: gelu(x) = max(x,0) - |x|/2 * poly(t) * exp(-x^2/2)
 // (bf16 kernels only; the f32 parity kernels keep erff)

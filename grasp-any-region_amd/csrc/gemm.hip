@@ -360,6 +360,10 @@ extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t strea
                       "gar_gemm: QKV_ROPE args");
     if (e == GAR_EPI_QKV_ROPE)      // the compact (sin, cos)-pair table goes with the per-wave epilogue, which writes v head-major
         GAR_CHECK_ARG(p.qkv_cos || p.qkv_v, "gar_gemm: QKV_ROPE with the compact table (qkv_cos == NULL) needs qkv_v");
+    if (p.norm_folded)
+        GAR_CHECK_ARG(dtype == GAR_BF16 && p.M <= 64 && !p.norm_w && p.split_k <= 1 &&
+                          (e == GAR_EPI_NONE || e == GAR_EPI_SWIGLU || e == GAR_EPI_BIAS),
+                      "gar_gemm: norm_folded is built for the bf16 decode GEMMs (M <= 64; NONE / BIAS / SWIGLU)");
     if (e == GAR_EPI_QKV_ROPE_LLM) {
         const int hd_ = p.qkv_head_dim;
         GAR_CHECK_ARG(!p.bias && p.qkv_q && p.qkv_k && p.qkv_v && p.qkv_sin && p.qkv_cos && p.qkv_heads > 0 && p.qkv_kv_heads > 0 &&

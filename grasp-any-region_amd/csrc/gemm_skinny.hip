@@ -28,8 +28,11 @@
 // and reads MFMA fragments back with conflict-free ds_read_b128 (chunk ^= (row >> 1) & 7, applied on the DMA source
 // side). Per-lane fragment loads from global memory touch 16 lines (half used) per instruction; for M = 64 the four
 // activation tiles re-read from L2 that way cost more than the weight stream itself (tools/bench_skinny.py).
-template <int EPI, int NT, int MT, bool NORM, bool STAGED>
-__global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
+// NORM: 0 none; 1 RMSNorm prologue with its gain (p.norm_w): x*g is the operand, sum x^2 accumulated on the VALU; 2 RMSNorm with
+// the gain folded into W (p.norm_folded): the operand is x itself and the row sums of squares come off the matrix pipe — one
+// extra MFMA pair per row tile and K step, x_tile x_tile^T, whose DIAGONAL is sum_k x[m][k]^2 (HBM-bound kernel: the pipe idles)
+template <int EPI, int NT, int MT, int NORM, bool STAGED>
+__global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,8 +67,12 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ssq[MT];
+    f32x4 ssm[MT];                 // NORM == 2: x_tile x_tile^T accumulators (lane (row, g) holds C[4 g + r][row])
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) ssq[mt] = 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
+        ssq[mt] = 0.f;
+        ssm[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- STAGED path: DMA tiles -> LDS -> fragments
     // The weight tiles of the next WD - 1 K steps are in flight while a step computes (narrow weight tiles, NT <= 2): a
@@ -143,14 +150,18 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
         if (ks + WD < ks1) stage_w(ks + WD);
         __builtin_amdgcn_sched_barrier(0);
         float ga[8], gb[8];
-        if (NORM) {
+        if (NORM == 1) {
             ld8(Gw + fq * 16 + k0, ga);
             ld8(Gw + fq * 16 + k0 + 8, gb);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16x8 x0 = xr0[mt], x1 = xr1[mt];
-            if (NORM) {
+            if (NORM == 2) {
+                ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, ssm[mt], 0, 0, 0);
+                ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, ssm[mt], 0, 0, 0);
+            }
+            if (NORM == 1) {
                 const u32x4 ua = __builtin_bit_cast(u32x4, x0), ub = __builtin_bit_cast(u32x4, x1);
                 u32x4 pa, pb;
 #pragma unroll
@@ -181,14 +192,14 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
             w1[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + k0 + 8));
         }
         float ga[8], gb[8];
-        if (NORM) {
+        if (NORM == 1) {
             ld8(Gw + fq * 16 + k0, ga);
             ld8(Gw + fq * 16 + k0 + 8, gb);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16x8 x0, x1;
-            if (NORM) {
+            if (NORM == 1) {
                 float xa[8], xb[8];
                 ld8(xp[mt] + k0, xa);
                 ld8(xp[mt] + k0 + 8, xb);
@@ -204,6 +215,10 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
             } else {
                 x0 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0);
                 x1 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0 + 8);
+                if (NORM == 2) {
+                    ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, ssm[mt], 0, 0, 0);
+                    ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, ssm[mt], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -236,13 +251,22 @@ __global__ __launch_bounds__((NT >= 4 || (NORM && MT >= 4)) ? 512 : 1024) void s
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<f32x4*>(red + (((wave * NT + t) * MT + mt) * 64 + lane) * 4) = acc[t][mt];
-    if (NORM) {
+    if (NORM == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float s = ssq[mt];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             if (lane < 16) red_ss[(wave * MT + mt) * 16 + lane] = s;
+        }
+    }
+    if (NORM == 2) {          // the diagonal: row i = 4 g + r of column i sits in lane (row = i, g = i >> 2), register i & 3
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 d = ssm[mt];
+            const int r = frow & 3;
+            const float s = r == 0 ? d[0] : (r == 1 ? d[1] : (r == 2 ? d[2] : d[3]));
+            if (fq == (frow >> 2)) red_ss[(wave * MT + mt) * 16 + frow] = s;
         }
     }
     __syncthreads();
@@ -309,14 +333,18 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     static gar_once_per_device attr_once;
     if (attr_once.first()) {
         if constexpr (NT <= 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, true, false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
         }
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, false, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
     }
     // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, LDS (merge buffer, and the
@@ -335,11 +363,15 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_>), dim3(nb, nsplit), dim3(nw * 64), lds, s, p)
     if constexpr (NT <= 2) {
         if (p.norm_w) {
-            if (staged) LAUNCH_SK(true, true); else LAUNCH_SK(true, false);
+            if (staged) LAUNCH_SK(1, true); else LAUNCH_SK(1, false);
             return;
         }
     }
-    if (staged) LAUNCH_SK(false, true); else LAUNCH_SK(false, false);
+    if (p.norm_folded) {
+        if (staged) LAUNCH_SK(2, true); else LAUNCH_SK(2, false);
+        return;
+    }
+    if (staged) LAUNCH_SK(0, true); else LAUNCH_SK(0, false);
 #undef LAUNCH_SK
 }
 

@@ -64,12 +64,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
                 if (s < S && !isv) {
                     const float sc = isq ? q_scale : 1.0f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {   // q*cos + rotate_half(q)*sin
-                        const float o1 = x1[u][e] * c[e] + (-x2[u][e]) * sv[e];
-                        const float o2 = x2[u][e] * c[e] + x1[u][e] * sv[e];
-                        x1[u][e] = o1 * sc;
-                        x2[u][e] = o2 * sc;
-                    }
+                    for (int e = 0; e < 8; ++e) rope_half_pair(x1[u][e], x2[u][e], c[e], sv[e], sc, x1[u][e], x2[u][e]);
                 }
                 if (isq && s < Spad) {
                     T* o = Q + (((int64_t)b * Hq + head) * Spad + s) * HD;
@@ -112,13 +107,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
         const float* sp = sn + (int64_t)rp * HALF + i8;
         const float sc = head < Hq ? q_scale : 1.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float c = cp[e], sv = sp[e];
-            const float o1 = x1[e] * c + (-x2[e]) * sv;
-            const float o2 = x2[e] * c + x1[e] * sv;
-            x1[e] = o1 * sc;
-            x2[e] = o2 * sc;
-        }
+        for (int e = 0; e < 8; ++e) rope_half_pair(x1[e], x2[e], cp[e], sp[e], sc, x1[e], x2[e]);
         T* o = head < Hq ? Q + (((int64_t)b * Hq + head) * Spad) * HD
                          : Kc + (((int64_t)b * Hkv + (head - Hq)) * Smax + p0) * HD;
         st8(o + i8, x1);

@@ -34,7 +34,7 @@ class GemmParams(C.Structure):
                 ("split_k", C.c_int32), ("partial", C.c_void_p), ("qkv_v", C.c_void_p),
                 ("row_scale", C.c_void_p), ("row_stats", C.c_void_p),
                 ("qkv_kv_heads", C.c_int32), ("qkv_kv_stride", C.c_int32), ("qkv_pos0", C.c_int32),
-                ("qkv_pos_dev", C.c_void_p), ("qkv_left_pad", C.c_void_p)]
+                ("qkv_pos_dev", C.c_void_p), ("qkv_left_pad", C.c_void_p), ("norm_folded", C.c_int32)]
 
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -60,6 +60,7 @@ SIGNATURES = {
     "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
     "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "gar_attention_decode_qkv": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp], _i),
     "gar_pool2x2":([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "gar_pool_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp], _i),

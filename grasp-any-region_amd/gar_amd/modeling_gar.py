@@ -172,6 +172,8 @@ class GARModel:
     # bf16 with FOLD_NORMS: RoPE, q scale and the KV-cache append run in the Llama prefill qkv GEMM's epilogue
     # (GAR_EPI_QKV_ROPE_LLM) — no [B*S, (Hq + 2 Hkv) hd] intermediate, no llm_qkv_post pass
     LLM_QKV_EPILOGUE = True
+    DECODE_GU_NORM_FOLDED = True  # bf16, 16 < B <= 64: post-attention RMSNorm inside the gate/up GEMM (gar_gemm_params.norm_folded)
+    DECODE_ATTN_TAKES_QKV = True  # bf16: the decode attention launch does llm_qkv_post's work (gar_attention_decode_qkv)
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
@@ -769,6 +771,8 @@ class GARModel:
                                       and F % (64 * self.DOWN_SPLIT_K) == 0 and C_l <= 4096) else 1
         partial = self._buf(key, "down_partial", (split, B, C_l), torch.float32) if split > 1 else None
         normed = None
+        gu_folded = (self.DECODE_GU_NORM_FOLDED and not fuse and self.dtype == torch.bfloat16 and B <= 64 and
+                     "gu_f" in self.layers[0])
         for li, ly in enumerate(self.layers):
             if fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
@@ -776,13 +780,19 @@ class GARModel:
                 if split == 1 or li == 0:
                     ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["qkv"], qkv)
-            ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
-                             left_pad=st["left_pad"])
-            ops.attention_decode(Q, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
-                                 kv_start=st["left_pad"])
+            # bf16: RoPE, q scale and the cache append run inside the attention launch (one launch instead of two)
+            if not (self.DECODE_ATTN_TAKES_QKV and
+                    ops.attention_decode_qkv(qkv, cos, sin, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, pos_dev,
+                                             q_scale, nsplit, dws, left_pad=st["left_pad"])):
+                ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
+                                 left_pad=st["left_pad"])
+                ops.attention_decode(Q, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
+                                     kv_start=st["left_pad"])
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
             if fuse:
                 ops.gemm(h, ly["gu"], ff, hip.EPI_SWIGLU, norm_w=ly["ln2"], norm_eps=t.rms_norm_eps)
+            elif gu_folded:     # W diag(g) + row sums of squares off the matrix pipe: no RMSNorm launch, no normalised copy
+                ops.gemm(h, ly["gu_f"], ff, hip.EPI_SWIGLU, norm_folded=True, norm_eps=t.rms_norm_eps)
             else:
                 ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
                 ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)

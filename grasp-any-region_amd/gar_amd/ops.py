@@ -38,10 +38,12 @@ def _chk(t: torch.Tensor, name: str):
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, bias=None, residual=None,
          gamma=None, pos=None, tokens_in: int = 0, tokens_out: int = 0, token_offset: int = 0, norm_w=None,
          norm_eps: float = 0.0, partial: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-         row_stats: Optional[torch.Tensor] = None):
+         row_stats: Optional[torch.Tensor] = None, norm_folded: bool = False):
     """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T). `a`, `out`, `residual` may be row-strided 2-D views.
     ``partial`` fp32 [split_k, M, N] (decode GEMMs, EPI_NONE): the K range is cut into split_k slices whose products go
-    there instead of ``out`` (pass ``out=None``); ``splitk_residual_rmsnorm`` reduces them."""
+    there instead of ``out`` (pass ``out=None``); ``splitk_residual_rmsnorm`` reduces them.
+    ``norm_folded`` (bf16, M <= 64): ``w`` carries an RMSNorm's gain (W diag(g)); the kernel takes rsqrt(mean(a^2) + norm_eps)
+    per row from the tiles of ``a`` it streams and scales the accumulator rows — no norm launch in front of the GEMM."""
     assert a.dim() == 2
     M, K = a.shape
     p = GemmParams()
@@ -65,6 +67,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     p.pos = ptr(pos)
     p.tokens_in, p.tokens_out, p.token_offset = tokens_in, tokens_out, token_offset
     p.norm_w, p.norm_eps = ptr(norm_w), norm_eps
+    p.norm_folded = 1 if norm_folded else 0
     # folded norm (include/gar_hip.h): row_scale [M] fp32 multiplies the accumulator rows; row_stats [M, ceil(N/64), 2] fp32
     # receives (sum, sum of squares) of the rounded outputs per 64-column strip
     if row_scale is not None:
@@ -353,6 +356,19 @@ def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits,
     check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
                                      ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
           "gar_attention_decode")
+
+
+def attention_decode_qkv(qkv, cos, sin, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev, q_scale, max_splits, workspace,
+                         left_pad=None) -> bool:
+    """llm_qkv_post (S = 1) + attention_decode in one launch: ``qkv`` [B, (Hq + 2 Hkv) hd] raw GEMM output of the step, the
+    new key / value rows are appended to ``Kc`` / ``Vc`` at row pos_dev[0]. False (nothing launched) in parity mode."""
+    rc = lib().gar_attention_decode_qkv(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Kc), ptr(Vc), ptr(O), B, Hq,
+                                        Hkv, hd, Smax, ptr(pos_dev), ptr(left_pad), q_scale, max_splits, ptr(workspace),
+                                        stream())
+    if rc == hip.ERR_UNSUPPORTED:
+        return False
+    check(rc, "gar_attention_decode_qkv")
+    return True
 
 
 def attention_decode_workspace(B, Hq, hd, max_splits) -> int:

@@ -118,6 +118,11 @@ typedef struct gar_gemm_params {
     int32_t qkv_kv_heads, qkv_kv_stride, qkv_pos0;
     const int32_t* qkv_pos_dev;
     const int32_t* qkv_left_pad;
+    /* bf16, M <= 64 (decode GEMMs; GAR_EPI_NONE / BIAS / SWIGLU), ABI v9: the RMSNorm in front of the GEMM with its gain folded
+     * into W (W = W0 diag(g), the weight row_scale's consumers use): C = epilogue(rsqrt(mean_k A[m][k]^2 + norm_eps) * (A W^T)).
+     * The row sums of squares are taken from the A tiles the kernel streams anyway (one extra MFMA pair per tile): no norm
+     * launch, no normalised copy of A. */
+    int32_t norm_folded;
 } gar_gemm_params;
 
 /* Replaces: every nn.Linear / cuBLAS GEMM on the path — timm Eva qkv/proj/fc1/fc2 (via
@@ -232,6 +237,15 @@ int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits);
 int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq, int Hkv,
                          int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits,
                          void* workspace, gar_stream_t stream);
+/* gar_llm_qkv_post (S = 1) and gar_attention_decode as ONE launch (ABI v9; bf16): `qkv` [B, (Hq+2Hkv)*hd] is the step's raw
+ * qkv GEMM output. Every workgroup applies the half-split RoPE at position pos_dev[0] - left_pad[b] and q_scale to its query
+ * heads while it loads them; the workgroup that owns the last kv tile of (b, kv head) rotates the new key, appends key and
+ * value to cache row pos_dev[0] of Kc / Vc and attends over rows left_pad[b] .. pos_dev[0]. Same arithmetic, bit for bit,
+ * as the two calls (HF: apply_rotary_pos_emb + DynamicCache.update + attention of one greedy step, modeling_gar.py:418-426).
+ * GAR_ERR_UNSUPPORTED (nothing launched) for GAR_F32: parity mode keeps the two calls. */
+int gar_attention_decode_qkv(int dtype, const void* qkv, const float* cos, const float* sin, void* Kc, void* Vc, void* O,
+                             int B, int Hq, int Hkv, int hd, int Smax, const int32_t* pos_dev, const int32_t* left_pad,
+                             float q_scale, int max_splits, void* workspace, gar_stream_t stream);
 
 /* PerceptionLMAdaptiveAvgPooling (modeling_perception_lm.py:47-60): per tile [g*g, C] -> [(g/2)^2, C], exact 2x2
  * mean. Input tile t starts at row t*in_tile_tokens + in_token_offset of x (lets the projector run over the

@@ -529,6 +529,7 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     ks, vs = [rk], [rv]
     for step in range(2):
         x1 = q(rnd(B, 1, Wd, seed=23 + step), dt)
+        K0, V0 = Kc.clone(), Vc.clone()                                           # caches before this step's append
         ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vc, B, 1, 1, Hq, Hkv, hd, Smax,
                          0, counters[0:1], scale)
         ops.attention(Q1, Kc, Vc, o1, B, Hq, Hkv, hd, 1, 1, 0, Smax, causal=False, kv_len_dev=counters[1:2], v_row_major=True)
@@ -538,6 +539,13 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
             o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
             ops.attention_decode(Q1, Kc, Vc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws)
             o2s.append(o2)
+            # the same step as ONE launch (RoPE + q scale + cache append inside the attention): bit-identical, caches included
+            Kf, Vf, o3 = K0.clone(), V0.clone(), torch.full_like(o2, float("nan"))
+            took = ops.attention_decode_qkv(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Kf, Vf, o3, B, Hq, Hkv, hd, Smax,
+                                            counters[0:1], scale, nsplit, ws)
+            assert took == (dt == torch.bfloat16)
+            if took:
+                assert torch.equal(o3, o2) and torch.equal(Kf, Kc) and torch.equal(Vf, Vc)
         ops.counter_add(counters, 1)
         q1, k1, v1 = ref_qkv(x1, S + step)
         ks.append(k1)
@@ -604,6 +612,7 @@ def test_llm_left_padded_batch_attention(dev, dt, hd):
     Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
     for step in range(2):
         x1 = q(rnd(B, 1, Wd, seed=43 + step), dt)
+        K0, V0 = Kc.clone(), Vc.clone()
         ops.llm_qkv_post(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Q1, Kc, Vc, B, 1, 1, Hq, Hkv, hd, Smax,
                          0, counters[0:1], scale, left_pad=lp)
         outs = []
@@ -612,6 +621,12 @@ def test_llm_left_padded_batch_attention(dev, dt, hd):
             o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
             ops.attention_decode(Q1, Kc, Vc, o2, B, Hq, Hkv, hd, Smax, counters[1:2], nsplit, ws, kv_start=lp)
             outs.append(o2)
+            Kf, Vf, o3 = K0.clone(), V0.clone(), torch.full_like(o2, float("nan"))
+            if ops.attention_decode_qkv(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Kf, Vf, o3, B, Hq, Hkv, hd, Smax,
+                                        counters[0:1], scale, nsplit, ws, left_pad=lp):
+                assert torch.equal(o3, o2) and torch.equal(Kf, Kc) and torch.equal(Vf, Vc)
+            else:
+                assert dt == torch.float32
         ops.counter_add(counters, 1)
         for b, pd in enumerate(pads):
             q1, k1, v1 = ref_qkv(x1[b:b + 1], S - pd + step)
@@ -847,6 +862,39 @@ def test_skinny_gemm_with_fused_rmsnorm(dev, dt, epi):
         out = torch.empty(M, Fd, dtype=dt, device=dev)
         ops.gemm(x.to(dev, dt), gu.to(dev, dt), out, hip.EPI_SWIGLU, norm_w=g.to(dev, dt), norm_eps=1e-5)
         close(out, F.silu(n @ gw.double().T) * (n @ uw.double().T), dt, extra=2.0)
+
+
+@pytest.mark.parametrize("M", [3, 17, 33, 64])
+@pytest.mark.parametrize("N", [768, 8192 + 64])
+def test_skinny_gemm_with_folded_rmsnorm(dev, M, N):
+    """decode path, gar_gemm_params.norm_folded: W carries the RMSNorm gain, the kernel takes the row sums of squares of the
+    activations off the matrix pipe (diagonal of x_tile x_tile^T) and scales the accumulator rows: equals the fp64
+    rmsnorm -> linear (-> SwiGLU) of the same bf16 activations; narrow (1-2 weight tiles per block) and wide (4) outputs."""
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    K = 2048
+    x = q(rnd(M, K, seed=140, scale=2.5) + 0.3, dt)
+    g = 1 + 0.1 * rnd(K, seed=141)
+    w = rnd(N, K, seed=142, scale=K ** -0.5)
+    wf = q(w * g[None, :], dt)                                     # W diag(g), rounded once
+    xd = x.double()
+    y = (xd @ wf.double().T) * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5)
+    out = torch.empty(M, N, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), wf.to(dev, dt), out, norm_folded=True, norm_eps=1e-5)
+    close(out, y, dt, extra=1.5)
+    Fd = N // 2
+    gu = torch.stack([wf[:Fd].view(Fd // 16, 16, K), wf[Fd:].view(Fd // 16, 16, K)], 1).reshape(N, K)
+    o2 = torch.empty(M, Fd, dtype=dt, device=dev)
+    ops.gemm(x.to(dev, dt), gu.to(dev, dt), o2, hip.EPI_SWIGLU, norm_folded=True, norm_eps=1e-5)
+    close(o2, F.silu(y[:, :Fd]) * y[:, Fd:], dt, extra=2.0)
+
+
+def test_gemm_norm_folded_refuses_large_m(dev):
+    from gar_amd import hip, ops
+    dt = torch.bfloat16
+    with pytest.raises(hip.GarError, match="norm_folded"):
+        ops.gemm(torch.zeros(65, 128, dtype=dt, device=dev), torch.zeros(64, 128, dtype=dt, device=dev),
+                 torch.zeros(65, 64, dtype=dt, device=dev), norm_folded=True, norm_eps=1e-5)
 
 
 @pytest.mark.parametrize("M", [17, 32, 40, 64])
