@@ -1009,20 +1009,20 @@ def _fold_ln(W, b, gamma, beta):
 
 def test_row_rstd_and_stats_finalize(dev):
     from gar_amd import ops
-    M, D = 1000, 1024
-    x = q(rnd(M, D, seed=90) * 2.0 + 0.7, torch.bfloat16)
-    xd = x.to(dev, torch.bfloat16)
-    for rms in (False, True):
-        out = torch.empty(M, dtype=torch.float32, device=dev)
-        ops.row_rstd(xd, 1e-5, rms, out)
-        var = x.double().pow(2).mean(1) if rms else x.double().var(1, unbiased=False)
-        ref = (var + 1e-5).rsqrt()
-        assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
-        # the same from per-strip partials
-        st = torch.stack([x.double().view(M, 16, 64).sum(-1), x.double().view(M, 16, 64).pow(2).sum(-1)], -1).float()
-        out2 = torch.empty(M, dtype=torch.float32, device=dev)
-        ops.row_stats_finalize(st.to(dev).contiguous(), D, 1e-5, rms, out2)
-        assert float((out2.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    for M, D in ((1000, 1024), (77, 2560), (3, 64)):          # 16 / 40 / 1 strips of 64 columns; rows not a multiple of 16
+        x = q(rnd(M, D, seed=90) * 2.0 + 0.7, torch.bfloat16)
+        xd = x.to(dev, torch.bfloat16)
+        for rms in (False, True):
+            out = torch.empty(M, dtype=torch.float32, device=dev)
+            ops.row_rstd(xd, 1e-5, rms, out)
+            var = x.double().pow(2).mean(1) if rms else x.double().var(1, unbiased=False)
+            ref = (var + 1e-5).rsqrt()
+            assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+            # the same from per-strip partials
+            st = torch.stack([x.double().view(M, D // 64, 64).sum(-1), x.double().view(M, D // 64, 64).pow(2).sum(-1)], -1).float()
+            out2 = torch.full((M,), float("nan"), dtype=torch.float32, device=dev)
+            ops.row_stats_finalize(st.to(dev).contiguous(), D, 1e-5, rms, out2)
+            assert float((out2.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "none_rms", "swiglu_rms"])
