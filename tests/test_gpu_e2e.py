@@ -444,6 +444,59 @@ def test_bf16_folded_norms_gar1b_dims():
     assert torch.equal(o2.logits[0], o2.logits[1]) and torch.equal(o2.logits[0, 0], folded.logits[0, 0])
 
 
+def test_bf16_fused_llm_paths_gar1b_dims():
+    """Round 3's fused Llama paths at GAR-1B dims (two layers each, 18 identical sequences so that the decode step takes the
+    16 < B <= 64 schedule): the prefill qkv GEMM with RoPE + q scale + cache append in its epilogue (LLM_QKV_EPILOGUE), the
+    decode attention that takes the raw qkv GEMM output (DECODE_ATTN_TAKES_QKV) and the post-attention RMSNorm inside the
+    gate/up GEMM (DECODE_GU_NORM_FOLDED), each against the same model with that switch off. The attention fusion changes no
+    arithmetic: bit-identical tokens and logits; the other two move rounding points: logits within the bf16 tolerance of each
+    other and of the f32 oracle."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b(**{"vision.depth": 2, "text.num_hidden_layers": 2})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16)
+    s = _sample(cfg, proc, 3, 1024, 1024, dtype=torch.bfloat16)
+    Wq = {k: v.to(torch.bfloat16).float() for k, v in W.items()}
+    ref_seq, ref_logits = _oracle(Wq, cfg, s, 1, attn_impl="sdpa")
+    B, n = 18, 4
+    batch = dict(input_ids=torch.cat([s["input_ids"]] * B), pixel_values=torch.cat([s["pixel_values"]] * B),
+                 global_mask_values=torch.cat([s["global_mask_values"]] * B), bboxes=s["bboxes"] * B,
+                 aspect_ratios=torch.cat([s["aspect_ratios"]] * B))
+    m = GARModel(cfg, W, torch.bfloat16)
+    assert m.LLM_QKV_EPILOGUE and m.DECODE_ATTN_TAKES_QKV and m.DECODE_GU_NORM_FOLDED and not m.qkv_f_permuted
+    fused = m.generate(**batch, max_new_tokens=n, return_logits=True)
+    assert "qkv" not in m._ws[("prefill",)]                       # the [B*S, (Hq + 2 Hkv) hd] intermediate was never allocated
+    assert "down_partial" in m._ws[("decode", B)]
+    lf = fused.logits.cpu()
+    assert torch.isfinite(lf).all()
+    for r in range(1, B):
+        assert torch.equal(lf[r], lf[0]), r
+    assert _rel_l2(lf[:1, 0], ref_logits[:, 0]) < BF16_LOGIT_TOL
+    # teacher-forced on the fused run's tokens so that every step compares like with like
+    m.DECODE_ATTN_TAKES_QKV = False
+    m._graphs.clear()                                             # the captured decode step holds the old launch sequence
+    two_launch = m.generate(**batch, max_new_tokens=n, return_logits=True, forced_tokens=fused.sequences)
+    assert torch.equal(two_launch.logits.cpu(), lf) and torch.equal(two_launch.sequences.cpu(), fused.sequences.cpu())
+    m.DECODE_ATTN_TAKES_QKV = True
+    m.DECODE_GU_NORM_FOLDED = False
+    m._graphs.clear()
+    plain_norm = m.generate(**batch, max_new_tokens=n, return_logits=True, forced_tokens=fused.sequences)
+    m.DECODE_GU_NORM_FOLDED = True
+    m.LLM_QKV_EPILOGUE = False                                    # head_dim 64: qkv_f is in the natural order either way
+    m._graphs.clear()
+    two_kernel_prefill = m.generate(**batch, max_new_tokens=n, return_logits=True, forced_tokens=fused.sequences)
+    assert "qkv" in m._ws[("prefill",)]
+    m.LLM_QKV_EPILOGUE = True
+    e_norm = max(_rel_l2(plain_norm.logits[:1, j], fused.logits[:1, j]) for j in range(n))
+    e_qkv = max(_rel_l2(two_kernel_prefill.logits[:1, j], fused.logits[:1, j]) for j in range(n))
+    print(f"fused Llama paths: norm-in-gate/up vs stand-alone norm rel-L2 {e_norm:.3e}; qkv epilogue vs gemm + qkv_post {e_qkv:.3e}")
+    assert torch.equal(plain_norm.logits[:, 0].cpu(), lf[:, 0])   # the first token comes out of the prefill: same path
+    assert 0.0 < e_norm < BF16_LOGIT_TOL and 0.0 < e_qkv < BF16_LOGIT_TOL      # > 0: the switched-off paths really ran
+
+
 def test_f32_parity_gar1b_dims_multi_region_one_layer():
     """BASELINE.json configs[2]: 4 masks per 1024^2 image, relationship prompt, GAR-1B shapes (one layer each):
     four 256-row RoI replays spliced into one ~5.5k-token sequence, f32 token parity with the oracle."""
