@@ -112,8 +112,8 @@ __device__ __forceinline__ void append_new_kv(const decode_qkv_args& fa, bf16_t*
 #define DA_KV_AUX 2
 #endif
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
-__global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                 const bf16_t* __restrict__ V, float* __restrict__ part,
+__global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* __restrict__ Q, bf16_t* K, bf16_t* V,      // K / V: appended to in fused mode
+                                                                 float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
                                                                  const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                  bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     const int t_lo = kv_lo >> 6;
     const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
     const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
-    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
     for (; t < t1; t += 4) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (fa.raw && t == ntiles - 1)           // the tile that holds the step's own row: this wave appends it
-            append_new_kv<HD, true, true>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+            append_new_kv<HD, true, true>(fa, Kp, Vp, ks, vs, b, Hq, Hkv, kvh, lane,
                                           kv_len - 1, rp, [](int r) { return (r >> 1) & 7; }, [](int r) { return ((r >> 1) & 1) << 2; });
         bf16x8 kf[2][NKD], vf[NDB][4];
 #pragma unroll
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
 //   wait K(t) [vmcnt: the 16 V pieces behind it may stay out] -> K fragments -> re-arm K with tile t+4 -> QK^T, softmax
 //   wait V(t) [the 16 K pieces just issued may stay out]      -> V fragments -> re-arm V             -> PV
 // 128 KiB + merge buffer per block: one block (4 waves) per CU, the same 128 KiB of loads in flight per CU.
-__global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                    const bf16_t* __restrict__ V, float* __restrict__ part,
+__global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t* __restrict__ Q, bf16_t* K, bf16_t* V,
+                                                                    float* __restrict__ part,
                                                                     int Hq, int Hkv, int kv_stride,
                                                                     const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
                                                                     bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
     const int t_lo = kv_lo >> 6;
     const int per = (ntiles - t_lo + nsplit - 1) / nsplit;
     const int t0 = t_lo + split * per, t1 = min(ntiles, t0 + per);
-    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
     const unsigned slab = (unsigned)kv_stride * HD * 2u;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K(t) landed; the 16 V(t) pieces may still be out
         const bool own_new = fa.raw && t == ntiles - 1;            // the tile that holds the step's own row (this wave's last tile)
         if (own_new)
-            append_new_kv<HD, true, false>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+            append_new_kv<HD, true, false>(fa, Kp, Vp, ks, vs, b, Hq, Hkv, kvh, lane,
                                            kv_len - 1, rp, [](int r) { return r & 15; }, [](int r) { return (r & 3) << 2; });
         f32x16 s[2];
         {
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
         if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (own_new)                            // (the key row's global stores sit behind vmcnt(0) too: `more` is false here)
-            append_new_kv<HD, false, true>(fa, const_cast<bf16_t*>(Kp), const_cast<bf16_t*>(Vp), ks, vs, b, Hq, Hkv, kvh, lane,
+            append_new_kv<HD, false, true>(fa, Kp, Vp, ks, vs, b, Hq, Hkv, kvh, lane,
                                            kv_len - 1, rp, [](int r) { return r & 15; }, [](int r) { return (r & 3) << 2; });
         bf16x8 vf[NDB][4];
 #pragma unroll
@@ -556,7 +556,7 @@ extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max
     return (int64_t)B * Hq * max_splits * (hd + 2) * 4;
 }
 
-static int launch_decode(const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq, int Hkv, int hd, int Smax,
+static int launch_decode(const void* q, void* Kc, void* Vc, void* O, int B, int Hq, int Hkv, int hd, int Smax,
                          const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits, void* workspace,
                          const decode_qkv_args& fa, gar_stream_t stream) {
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
@@ -575,8 +575,8 @@ static int launch_decode(const void* q, const void* Kc, const void* Vc, void* O,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
-        hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
+        hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)Kc,
+                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
@@ -587,8 +587,8 @@ static int launch_decode(const void* q, const void* Kc, const void* Vc, void* O,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds128_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
-        hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)Kc,
-                           (const bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
+        hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)Kc,
+                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
@@ -608,7 +608,9 @@ extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, co
         return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, 0, stream);
     GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
     const decode_qkv_args none = {nullptr, nullptr, nullptr, 0.f};
-    return launch_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, kv_start, max_splits, workspace, none, stream);
+    // (the plain form only reads the caches)
+    return launch_decode(q, const_cast<void*>(Kc), const_cast<void*>(Vc), O, B, Hq, Hkv, hd, Smax, kv_len_dev, kv_start, max_splits,
+                         workspace, none, stream);
 }
 
 // gar_llm_qkv_post (S = 1) + gar_attention_decode in ONE launch (bf16): see decode_qkv_args. GAR_ERR_UNSUPPORTED (nothing
