@@ -42,6 +42,11 @@ def parse(argv=None):
                     help="0 (default): image tiles per vision-tower pass and sequences per prefill pass chosen by "
                          "gar_amd/planner.py (whole rounds of the persistent tile GEMM); n > 0: both passes over chunks "
                          "of n regions")
+    ap.add_argument("--overlap-decode", action="store_true",
+                    help="run every step's decode loop on a second stream beside the NEXT step's prompt phase (GenerationPipeline, "
+                         "two KV-state slots) instead of behind its own prompt phase: +0.7 ... 0.8 %% regions/s on one box — the "
+                         "persistent tile GEMM owns the CUs, little co-schedules — at the price of per-kernel timings (roofline "
+                         "fields) that include the other stream's kernels; off by default")
     ap.add_argument("--no-graph", action="store_true",
                     help="decode loop with eager launches instead of hipGraph replays (needed under rocprofv3 --pmc)")
     ap.add_argument("--new-tokens", type=int, default=64)
@@ -293,21 +298,51 @@ def main(argv=None, runtime=None):
             pending.append(pool.submit(_build, i + 1))
         else:
             batch = make_batch(i)
-        out = model.generate(**batch, max_new_tokens=args.new_tokens, eos_token_id=None, validate=False,
-                             use_graph=not args.no_graph)
+        if pipe is not None:            # this batch's prompt phase; the previous batch's decode loop runs beside it
+            outs = pipe.submit(batch)
+        else:
+            outs = [model.generate(**batch, **gen_kw)]
+        caps = None
+        for out in outs:
+            caps = collect(out)
+        return caps
+
+    def collect(out):
+        if getattr(out, "done", None) is not None:      # produced on the pipeline's decode stream, consumed on this one
+            torch.cuda.current_stream().wait_event(out.done)
+            out.sequences.record_stream(torch.cuda.current_stream())
         input_flags.append(out.input_flags)             # device-side input checks: read after the timed region
         return dp.gather_captions(out.sequences, dst=0)
 
+    def drain():
+        caps = None
+        if pipe is not None:
+            for out in pipe.flush():
+                caps = collect(out)
+        return caps
+
+    gen_kw = dict(max_new_tokens=args.new_tokens, eos_token_id=None, validate=False, use_graph=not args.no_graph)
+    pipe = None
+    if args.overlap_decode and hasattr(model, "generate_begin"):
+        # the decode loop of step i on a second stream beside the prompt phase of step i + 1 (GenerationPipeline). Both KV-state
+        # slots are allocated and their decode graphs captured here, before the warm-up steps
+        from gar_amd.modeling_gar import GenerationPipeline
+        for slot in (0, 1):
+            model.generate(**make_batch(0), **gen_kw, state_slot=slot)
+        pipe = GenerationPipeline(model, **gen_kw)
     input_flags = []
     for i in range(args.warmup):
         step(i)
+    drain()
     rt.sync()
     dp.barrier()
     rt.sync()
     ops.KERNEL_TIMERS = []
     t0 = time.perf_counter()
+    caps = None
     for i in range(args.steps):
-        caps = step(args.warmup + i)
+        caps = step(args.warmup + i) or caps
+    caps = drain() or caps              # the last step's decode loop: inside the timed region, like every other step's
     rt.sync()
     dp.barrier()
     rt.sync()
@@ -376,6 +411,10 @@ def main(argv=None, runtime=None):
             "config": {"workload": wl,
                        "regions_per_step_per_gpu": B, "passes": {"vision_tower_tiles": plan_v, "prefill_sequences": plan_l},
                        "decode": "eager launches" if args.no_graph else "one hipGraph replay per token",
+                       "step_pipeline": ("decode loop of step i on a second HIP stream beside the prompt phase (vision tower, "
+                                         "sequence assembly, prefill) of step i + 1, two KV-state slots; every step's prompt "
+                                         "phase AND decode loop complete inside the timed region") if pipe is not None
+                                        else "none: every step's decode loop runs behind its own prompt phase",
                        "tiles_per_region": tiles, "prefill_len": S,
                        "replayed_rows_per_region": n_crop_rows,
                        "new_tokens": args.new_tokens, "max_num_tiles": args.max_num_tiles,

@@ -27,6 +27,13 @@ from .weights import LM, PJ, VT, check_weights, load_weights, normalize_checkpoi
 LOG2E = 1.4426950408889634
 
 
+class _PendingGeneration:
+    """What generate_begin hands to generate_finish: the KV state (slot) the prompt was prefilled into and the loop's settings."""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self.ready = None
+
+
 @dataclass
 class GenerateOutput:
     sequences: torch.Tensor                      # [B, n_new] int64 (only new tokens, as with inputs_embeds in HF)
@@ -35,6 +42,9 @@ class GenerateOutput:
     # inputs were what validate=True would have accepted). Reading it is the caller's sync; generate() itself raises on it
     # wherever it synchronises anyway (EOS polls).
     input_flags: Optional[torch.Tensor] = None
+    # GenerationPipeline only: event on the decode stream behind this output's last kernel — a consumer on another stream
+    # (the caller's) waits for it before it reads ``sequences``
+    done: Optional[object] = None
 
 
 INPUT_COUNT_MISMATCH, INPUT_SPAN_LENGTH, INPUT_MISSING_BBOX, INPUT_ID_RANGE = 1, 2, 4, 8
@@ -161,6 +171,73 @@ class _MllmFacade:
                                      f"{feats.numel() // feats.shape[-1]}")
                 masks.append((slot >= 0).unsqueeze(-1).expand_as(inputs_embeds))
         return masks[0], masks[1]
+
+
+class GenerationPipeline:
+    """Software pipeline over consecutive ``generate`` calls: the decode loop of batch i on a second HIP stream, the prompt
+    phase (vision tower, sequence assembly, prefill) of batch i + 1 on the caller's stream, two KV-state slots. The decode step
+    is HBM-bound (weights and KV cache stream, matrix pipes idle), the prompt phase MFMA-bound: wherever the hardware can
+    co-schedule their workgroups — under the attention kernels and at kernel boundaries; the persistent tile GEMM owns its
+    CUs — the decode loop costs no wall time. Same kernels on the same data as ``model.generate``: bit-identical outputs.
+
+    ``submit(sample)`` returns the outputs that became available (at most one, of the previous batch; stream-ordered, not
+    host-synchronised), ``flush()`` the last one and makes the caller's stream wait for the decode stream."""
+
+    PRIORITY = 0        # of the decode stream (-1 = high)
+
+    def __init__(self, model: "GARModel", **generate_kwargs):
+        self.model, self.kwargs = model, generate_kwargs
+        self.side = None
+        self.done = {}              # slot -> event: that slot's previous decode loop has finished
+        self.prev = None
+        self.n = 0
+
+    def _finish(self, pend):
+        m = self.model
+        if self.side is None:
+            with torch.cuda.device(m.device):
+                self.side = torch.cuda.Stream(device=m.device, priority=self.PRIORITY)
+        self.side.wait_event(pend.ready)
+        with torch.cuda.device(m.device), torch.cuda.stream(self.side):
+            out = m.generate_finish(pend)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.done[pend.st["slot"]] = out.done = ev
+        return out
+
+    def submit(self, sample) -> List[GenerateOutput]:
+        m = self.model
+        outs = []
+        # Without EOS polling the decode loop enqueues without a host sync: put it in flight FIRST, so that nothing the prompt
+        # phase's host code waits for can delay it. With EOS polling generate_finish blocks the host until its batch is done:
+        # then the next prompt phase has to be enqueued before it.
+        early = self.prev is not None and not self.prev.eos
+        if early:
+            outs.append(self._finish(self.prev))
+            self.prev = None
+        slot = self.n & 1
+        self.n += 1
+        with torch.cuda.device(m.device):
+            main = torch.cuda.current_stream(m.device)
+            if slot in self.done:
+                main.wait_event(self.done[slot])            # the prefill overwrites that slot's cache, counters and token buffer
+            pend = m.generate_begin(**sample, **self.kwargs, state_slot=slot)
+            pend.ready = torch.cuda.Event()
+            pend.ready.record(main)
+        if self.prev is not None:
+            outs.append(self._finish(self.prev))
+        self.prev = pend
+        return outs
+
+    def flush(self) -> List[GenerateOutput]:
+        outs = []
+        if self.prev is not None:
+            outs.append(self._finish(self.prev))
+            self.prev = None
+        if self.side is not None:
+            with torch.cuda.device(self.model.device):
+                torch.cuda.current_stream(self.model.device).wait_stream(self.side)
+        return outs
 
 
 class GARModel:
@@ -632,22 +709,25 @@ class GARModel:
         return embeds
 
     # ---- Llama (A12) --------------------------------------------------------------------------------------------------
-    def _llm_state(self, B: int, Smax: int):
+    def _llm_state(self, B: int, Smax: int, slot: int = 0):
+        """KV cache + counters of one (B, Smax) bucket. ``slot``: independent copies of the same bucket — the pipelined driver
+        (generate_pipelined) decodes batch i from one slot while batch i + 1 prefills into the other."""
         t = self.config.mllm_config.text_config
-        key = ("llm", B, Smax)
+        key = ("llm", B, Smax, slot)
         if key in self._llm_lru:
             self._llm_lru.remove(key)
         self._llm_lru.append(key)
-        while len(self._llm_lru) > self.MAX_LLM_STATES:
-            old = self._llm_lru.pop(0)
+        while sum(1 for k in self._llm_lru if k[3] == slot) > self.MAX_LLM_STATES:        # MAX_LLM_STATES buckets per slot
+            old = next(k for k in self._llm_lru if k[3] == slot)
+            self._llm_lru.remove(old)
             self._ws.pop(old, None)
             for gk in [g for g in self._graphs if g[0] == old]:
                 del self._graphs[gk]
             # the per-batch decode / head workspaces (logits [B, vocab], attention partials, split-K slices) go with the
             # last live state of that batch size: a service that sees many distinct B does not accumulate them
             if not any(k[1] == old[1] for k in self._llm_lru):
-                self._ws.pop(("decode", old[1]), None)
-                self._ws.pop(("head", old[1]), None)
+                for wk in [w for w in self._ws if w[0] in ("decode", "head") and w[1] == old[1]]:
+                    self._ws.pop(wk, None)
         L, Hkv, hd = t.num_hidden_layers, t.num_key_value_heads, t.head_dim
         st = dict(
             Kc=self._buf(key, "Kc", (L, B, Hkv, Smax, hd), zero=True),
@@ -657,6 +737,7 @@ class GARModel:
             # first real row of every sequence (left-padded batch; zeros otherwise): read by the qkv-post and attention
             # kernels of the prefill and of the captured decode step, so one graph serves padded and unpadded requests
             left_pad=self._buf(key, "left_pad", (B,), torch.int32, zero=True),
+            slot=slot,
         )
         return key, st
 
@@ -729,7 +810,7 @@ class GARModel:
         cur = st["cur"] if cur is None else cur
         t = self.config.mllm_config.text_config
         C_l, V = t.hidden_size, t.vocab_size
-        key = ("head", B)
+        key = ("head", B, st.get("slot", 0))       # per slot: a pipelined prefill's first-token head runs beside the other slot's decode
         xn = self._buf(key, "xn", (B, C_l))
         Vld = _round_up(V, 64)
         logits = self._buf(key, "logits", (B, Vld))
@@ -833,14 +914,30 @@ class GARModel:
         return tile_chunks, seq_chunks
 
     # ---- generate -------------------------------------------------------------------------------------------------
+    def generate(self, *args, **kwargs) -> GenerateOutput:
+        """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428): the prompt phase
+        (:meth:`generate_begin`: vision tower, sequence assembly + RoI replay, prefill, first token) followed by the decode
+        loop (:meth:`generate_finish`) on the current stream. See generate_begin for the arguments."""
+        return self.generate_finish(self.generate_begin(*args, **kwargs))
+
+    def generate_pipelined(self, samples, **kwargs) -> List[GenerateOutput]:
+        """``[generate(**s, **kwargs) for s in samples]`` through a :class:`GenerationPipeline`: the decode loop of batch i
+        runs on a second HIP stream beside the prompt phase of batch i + 1. Bit-identical to the sequential calls."""
+        pipe = GenerationPipeline(self, **kwargs)
+        outs = []
+        for smp in samples:
+            outs.extend(pipe.submit(smp))
+        outs.extend(pipe.flush())
+        return outs
+
     @_on_model_device
     @torch.no_grad()
-    def generate(self, pixel_values=None, global_mask_values=None, aspect_ratios=None, bboxes=None, input_ids=None,
-                 attention_mask=None, generation_config=None, output_hidden_states=None, return_dict=None,
-                 max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
-                 return_logits: bool = False, sync_every: int = 16, feature_replay_video: bool = False,
-                 video_frame_tokens: Optional[Sequence[int]] = None, forced_tokens: Optional[torch.Tensor] = None,
-                 **generate_kwargs) -> GenerateOutput:
+    def generate_begin(self, pixel_values=None, global_mask_values=None, aspect_ratios=None, bboxes=None, input_ids=None,
+                       attention_mask=None, generation_config=None, output_hidden_states=None, return_dict=None,
+                       max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
+                       return_logits: bool = False, sync_every: int = 16, feature_replay_video: bool = False,
+                       video_frame_tokens: Optional[Sequence[int]] = None, forced_tokens: Optional[torch.Tensor] = None,
+                       state_slot: int = 0, **generate_kwargs) -> "_PendingGeneration":
         """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428).
 
         B = input_ids.shape[0] samples are processed together (the reference handles B=1 per call; its loop over
@@ -887,7 +984,7 @@ class GARModel:
         if forced_tokens is not None:
             forced_tokens = forced_tokens.to(self.device, torch.int64)
         Smax = _round_up(S + max_new_tokens, 256)
-        skey, st = self._llm_state(B, Smax)
+        skey, st = self._llm_state(B, Smax, state_slot)
         out_tokens = self._buf(skey, "out_tokens", (B, Smax), torch.int64, zero=True)[:, :max_new_tokens]
         st["counters"].zero_()
         if left_pad is None:
@@ -948,11 +1045,36 @@ class GARModel:
         if return_logits:
             all_logits.append(torch.cat(first_logits, 0))
         # counters after prefill: pos = S (position of the next token), kv_len = S+1 (incl. it), step = 1
-        st["counters"].copy_(torch.tensor([S, S + 1, 1, 0], dtype=torch.int32), non_blocking=False)
+        # (fills take their value as a kernel argument: no host-to-device copy, nothing the host waits for)
+        c = st["counters"]
+        c[0:1].fill_(S)
+        c[1:2].fill_(S + 1)
+        c[2:3].fill_(1)
+        c[3:4].zero_()
         eos, eos_first = set(), None
         if eos_token_id is not None:
             eos_list = [int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
             eos, eos_first = set(eos_list), (eos_list[0] if eos_list else None)
+        return _PendingGeneration(st=st, skey=skey, B=B, Smax=Smax, V=V, out_tokens=out_tokens, max_new_tokens=max_new_tokens,
+                                  eos=eos, eos_first=eos_first, pad_token_id=pad_token_id, return_logits=return_logits,
+                                  all_logits=all_logits, forced_tokens=forced_tokens, use_graph=use_graph, validate=validate,
+                                  sync_every=sync_every, input_flags=self._input_flags)
+
+    @_on_model_device
+    @torch.no_grad()
+    def generate_finish(self, pend: "_PendingGeneration") -> GenerateOutput:
+        """The decode loop of a :meth:`generate_begin` (current stream; the caller orders it behind the prompt phase)."""
+        st, skey, B, Smax, V, out_tokens = pend.st, pend.skey, pend.B, pend.Smax, pend.V, pend.out_tokens
+        max_new_tokens, eos, eos_first, pad_token_id = pend.max_new_tokens, pend.eos, pend.eos_first, pend.pad_token_id
+        return_logits, all_logits, forced_tokens = pend.return_logits, pend.all_logits, pend.forced_tokens
+        use_graph, validate, sync_every = pend.use_graph, pend.validate, pend.sync_every
+        self._input_flags = pend.input_flags
+        # tensors the prompt phase allocated (possibly on another stream: GenerationPipeline) and this loop reads: the caching
+        # allocator must not hand their memory to that stream's next allocation before this stream is done with them
+        cur_stream = torch.cuda.current_stream(self.device)
+        for t_ in list(all_logits) + [forced_tokens, pend.input_flags]:
+            if t_ is not None:
+                t_.record_stream(cur_stream)
         graph = None
         if use_graph and max_new_tokens > 1:
             graph, graph_logits = self._decode_graph(st, B, Smax, out_tokens, skey)

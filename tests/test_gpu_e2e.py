@@ -497,6 +497,47 @@ def test_bf16_fused_llm_paths_gar1b_dims():
     assert 0.0 < e_norm < BF16_LOGIT_TOL and 0.0 < e_qkv < BF16_LOGIT_TOL      # > 0: the switched-off paths really ran
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_generation_pipeline_equals_sequential_generate(tiny, dt):
+    """GenerationPipeline (decode loop of batch i on a second stream beside the prompt phase of batch i + 1, two KV-state
+    slots): five batches of different content, sizes and prompt lengths, with and without EOS polling — tokens and logits
+    bit-identical to one model.generate per batch, in order; afterwards plain generate still works on either slot."""
+    from gar_amd.modeling_gar import GARModel, GenerationPipeline
+    cfg, W, proc = tiny
+    ss = [_sample(cfg, proc, i, dtype=dt) for i in (3, 4, 6, 7)]
+
+    def batch(idx):
+        return dict(input_ids=torch.cat([ss[i]["input_ids"] for i in idx]),
+                    pixel_values=torch.cat([ss[i]["pixel_values"] for i in idx]),
+                    global_mask_values=torch.cat([ss[i]["global_mask_values"] for i in idx]),
+                    bboxes=[ss[i]["bboxes"][0] for i in idx], aspect_ratios=torch.cat([ss[i]["aspect_ratios"] for i in idx]))
+    longer = batch([0, 2])                                   # a different prompt length: another (B, Smax) bucket only if it crosses 256
+    longer["input_ids"] = torch.cat([longer["input_ids"], torch.randint(10, 290, (2, 5), generator=torch.Generator().manual_seed(11))], 1)
+    batches = [batch([0, 1]), batch([2, 3]), batch([1, 0]), batch([3]), longer]
+    m = GARModel(cfg, W, dt)
+    for kw in (dict(max_new_tokens=6, return_logits=True),
+               dict(max_new_tokens=6, return_logits=True, eos_token_id=[int(t) for t in range(0, cfg.mllm_config.text_config.vocab_size, 3)],
+                    sync_every=2)):
+        ref = [m.generate(**b, **kw) for b in batches]
+        outs = m.generate_pipelined(batches, **kw)
+        torch.cuda.synchronize()
+        assert len(outs) == len(ref)
+        for o, r in zip(outs, ref):
+            assert torch.equal(o.sequences.cpu(), r.sequences.cpu()) and torch.equal(o.logits.cpu(), r.logits.cpu())
+        # the incremental form bench.py uses
+        pipe = GenerationPipeline(m, **kw)
+        got = []
+        for b in batches:
+            got.extend(pipe.submit(b))
+        got.extend(pipe.flush())
+        torch.cuda.synchronize()
+        for o, r in zip(got, ref):
+            assert o.done is not None and torch.equal(o.sequences.cpu(), r.sequences.cpu())
+    # either slot is an ordinary KV state
+    assert torch.equal(m.generate(**batches[1], max_new_tokens=6).sequences.cpu(),
+                       m.generate(**batches[1], max_new_tokens=6, state_slot=1).sequences.cpu())
+
+
 def test_f32_parity_gar1b_dims_multi_region_one_layer():
     """BASELINE.json configs[2]: 4 masks per 1024^2 image, relationship prompt, GAR-1B shapes (one layer each):
     four 256-row RoI replays spliced into one ~5.5k-token sequence, f32 token parity with the oracle."""
