@@ -36,6 +36,22 @@ def test_code_objects_are_gfx950_only():
         assert targets and all("gfx950" in t for t in targets), targets
 
 
+def test_library_links_no_vendor_math_library():
+    """every device computation is this repo's own HIP code: libgar_hip.so depends on the HIP runtime only — no hipBLASLt /
+    rocBLAS / MIOpen / composable-kernel library — and the host package calls no torch math on the path (torch.mm and
+    friends appear in tools/ as calibration only)."""
+    so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", "libgar_hip.so")
+    out = subprocess.run(["ldd", so], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for lib in ("hipblas", "rocblas", "miopen", "hipblaslt", "rocsparse", "hipdnn"):
+        assert lib not in out.stdout.lower(), (lib, out.stdout)
+    pkg = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd")
+    for f in ("modeling_gar.py", "ops.py"):
+        src = open(os.path.join(pkg, f)).read()
+        for call in ("torch.mm(", "torch.matmul(", "torch.bmm(", "F.linear(", "scaled_dot_product_attention", "torch.softmax("):
+            assert call not in src, (f, call)
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd")
     for f in os.listdir(pkg):
