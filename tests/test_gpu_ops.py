@@ -483,7 +483,7 @@ def test_attention_f32_row_major_v_equals_transposed(dev, hd, causal):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("hd", [64, 128])
-@pytest.mark.parametrize("S", [70, 333, 129])
+@pytest.mark.parametrize("S", [70, 333, 129, 127, 64])      # 127 / 64: the decode steps' own rows are the last / first row of a kv tile
 def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
     """llm_qkv_post (half-split RoPE, GQA, append to the row-major K / V caches) + causal prefill attention, then two
     single-token decode steps with the kv length read from device memory."""
