@@ -69,6 +69,14 @@ def parse(argv=None):
                          "image tiles into LDS)")
     ap.add_argument("--vit-v-transpose", action="store_true",
                     help="A/B: ViT v through gar_vit_v_transpose + Vt attention instead of the row-major form")
+    ap.add_argument("--runtime", default=None,
+                    help="module:attr of a runtime object replacing GpuRuntime (tests/bench_stub.py: a CPU stub under gloo, so that "
+                         "the N > 1 control flow and the self-launch run on a box without GPUs); never set for a measurement")
+    ap.add_argument("--decode-probe-steps", type=int, default=2,
+                    help="eager decode steps timed kernel by kernel AFTER the timed region (rank 0) for the roofline_other entries of "
+                         "the kernels that run inside the hipGraph during it (decode attention, decode GEMVs); 0 = off")
+    ap.add_argument("--no-prune-last-layer", action="store_true",
+                    help="A/B: the last Llama prefill layer over all S rows (the reference's computation) instead of its last row only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args(argv)
@@ -222,6 +230,8 @@ class GpuRuntime:
             model.w_patch_gather = None
         if args.vit_v_transpose:
             model.VIT_V_ROW_MAJOR = False
+        if args.no_prune_last_layer:
+            model.PRUNE_LAST_PREFILL_LAYER = False
         return model, W
 
     def build_batches(self, args, cfg, rank, world, device):
@@ -230,20 +240,63 @@ class GpuRuntime:
         return build_batches(cfg, dproc, rank, world, args.batch, args.pool, device, args.workload, args.distinct_samples)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves — the same command the driver
+    documents (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    ...`), one process per GPU — and pass their output and exit code through. The scaling line must not depend on how the caller
+    spells the launch (VERDICT r3 #3)."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def load_runtime(spec):
+    import importlib
+    mod, _, attr = spec.partition(":")
+    obj = getattr(importlib.import_module(mod), attr)
+    return obj() if isinstance(obj, type) else obj
+
+
 def main(argv=None, runtime=None):
     args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and runtime is None:
+        rc = self_launch(args, argv)
+        if rc:
+            raise SystemExit(rc)
+        return
     from gar_amd import GARConfig, dp, ops
     from gar_amd.processing import GARProcessor
-    rt = runtime or GpuRuntime()
+    rt = runtime or (load_runtime(args.runtime) if args.runtime else GpuRuntime())
     rank, local, world = dp.init_distributed(rt.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node has to equal --gpus "
+                         f"(a plain `python bench.py --gpus N` launches its own ranks)")
     device = rt.device_of(local)
     if world > 1:       # N ranks share the box's cores (weight synthesis on rank 0, sample building, tokenisation)
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     cfg = getattr(GARConfig, args.model)()
     proc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles)
     model, W = rt.build_model(args, cfg, rank, device)
+    rt.sync()
+    dp.barrier()
+    tb = time.perf_counter()
     model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
+    rt.sync()
+    bcast_s = dp.max_over_ranks(time.perf_counter() - tb, device)
+    wt = getattr(model, "weight_tensors", None)
+    bcast_bytes = sum(t.numel() * t.element_size() for t in wt()) if wt else None
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")
     batches, one, n_distinct = rt.build_batches(args, cfg, rank, world, device)
@@ -346,7 +399,9 @@ def main(argv=None, runtime=None):
     rt.sync()
     dp.barrier()
     rt.sync()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, device)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(my_elapsed, device)
+    per_rank = dp.all_gather_floats(my_elapsed, device)             # every rank's own clock around the same K steps
     if rank == 0:       # every rank's [B, new_tokens] ids arrived on rank 0 in the last step
         assert caps is not None and len(caps) == world and all(tuple(c.shape) == (args.batch, args.new_tokens) for c in caps)
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
@@ -359,14 +414,26 @@ def main(argv=None, runtime=None):
 
     if rank != 0:
         return
+    # ---- kernels that run inside the hipGraph during the timed region (decode attention, decode GEMVs, split-K reduce):
+    # a few EAGER decode steps of the same batch after it, every launch bracketed by HIP events (rank 0)
+    probe = []
+    if args.decode_probe_steps > 0 and args.new_tokens > 1 and hasattr(model, "generate_finish"):
+        ops.KERNEL_TIMERS = []
+        model.generate(**make_batch(0), **{**gen_kw, "max_new_tokens": args.decode_probe_steps + 1, "use_graph": False})
+        rt.sync()
+        probe, ops.KERNEL_TIMERS = [t for t in ops.KERNEL_TIMERS if t[0].startswith("decode:")], None
     # ---- roofline of the dominant kernel (bf16 tile GEMM), live HIP-event timing over the timed region ---------------
-    agg = {}
-    for kind, flops, nbytes, e0, e1 in timers:
-        a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
-        a[0] += flops
-        a[1] += nbytes
-        a[2] += e0.elapsed_time(e1) * 1e-3
-        a[3] += 1
+    def fold(ts):
+        agg_ = {}
+        for kind, flops, nbytes, e0, e1 in ts:
+            a = agg_.setdefault(kind, [0.0, 0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += nbytes
+            a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += 1
+        return agg_
+    agg, pagg = fold(timers), fold(probe)
+    step_s = elapsed / args.steps
     roof = None
     if "gemm_tile_bf16" in agg:
         fl, nb, sec, cnt = agg["gemm_tile_bf16"]
@@ -377,7 +444,7 @@ def main(argv=None, runtime=None):
                 "algorithmic_bytes_per_launch": nb / cnt, "time_share_of_step": sec / elapsed}
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
         # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/ (newest round first)
-        for rnd in ("r3", "r2", "r1"):
+        for rnd in ("r4", "r3", "r2", "r1"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if args.workload == "single" and args.model == "gar_1b" and os.path.exists(pmc):
                 try:
@@ -404,6 +471,7 @@ def main(argv=None, runtime=None):
              f"(BASELINE.json {cfg_idx})"
     ids0 = batches[0]["input_ids"][0]
     plan_v, plan_l = model._plan_passes(B, tiles, S)
+    plan_l_ = plan_l
     n_crop_rows = int(sum(int((ids0 == t).sum()) for t in (batches[0].get("video_frame_tokens") or cfg.crop_tokens_ids)))
     line = {"metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -430,12 +498,43 @@ def main(argv=None, runtime=None):
                        "peak_device_memory_gib": rt.peak_mem_gib(device),
                        "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},
-            "roofline": roof}
-    if "gemm_skinny_bf16" in agg:
+            "roofline": roof,
+            **dp.describe(),
+            "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
+            "weight_broadcast": {"seconds": bcast_s, "bytes": bcast_bytes, "note": "one bucketed broadcast of the prepared weight "
+                                 "tensors from rank 0 before the warm-up (RCCL over xGMI; a no-op at N = 1)"}}
+    # ---- every other kernel family of the step: achieved / peak / frac and its share of the step -------------------------
+    other = line["roofline_other"] = {}
+
+    def mfma_entry(name, a, note=None):
+        fl, nb, sec, cnt = a
+        other[name] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                       "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                       "time_share_of_step": sec / elapsed}
+        if note:
+            other[name]["note"] = note
+
+    def hbm_entry(name, nb, sec, cnt, share, **extra):
+        other[name] = {"bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                       "time_share_of_step": share, **extra}
+
+    if "attn_full" in agg:
+        mfma_entry("attn_bf16_v2_kernel, ViT (non-causal, 1 + 1024 keys per tile and head)", agg["attn_full"],
+                   "flops = 4 * head_dim * queries * keys per (tile, head)")
+    if "attn_causal" in agg:
+        mfma_entry("attn_bf16_v2_kernel, Llama prefill (causal GQA)", agg["attn_causal"],
+                   "flops = 4 * head_dim * S (S + 1) / 2 per (sequence, query head): the causal triangle only")
+    if "gemm_skinny_bf16" in agg:       # prompt phase: the first-token head and the pruned last layer's B-row o / gate-up / down
         fl, nb, sec, cnt = agg["gemm_skinny_bf16"]
-        line["roofline_other"] = {"gemm_skinny_bf16(prefill head only; decode runs inside the hipGraph)":
-                                  {"bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "launches": cnt}}
+        hbm_entry("skinny_mt_bf16_kernel, prompt phase (lm_head of the first token + the pruned last prefill layer's B-row GEMMs)",
+                  nb, sec, cnt, sec / elapsed)
+    if "attn_decode" in agg:            # prompt phase: the pruned last layer's single-row attention over S cache rows
+        fl, nb, sec, cnt = agg["attn_decode"]
+        t_ = cfg.mllm_config.text_config
+        nb = sum(plan_l_) * t_.num_key_value_heads * S * t_.head_dim * 4.0 * args.steps
+        hbm_entry("decode_attn_lds_kernel, prompt phase (last prompt row of the pruned last prefill layer)", nb, sec, cnt,
+                  sec / elapsed)
     # HBM-bound RoI feature-replay pass (pool + embed/scatter + RoI replay), priced at SURVEY.md section 8d's ALGORITHMIC
     # bytes: the projector's grid rows read once + the sequence written once + the RoI cells (~90 MB per region at GAR-1B /
     # 1024^2). Since round 2 the pass IS that traffic: gar_pool_assemble pools on the way into the sequence and
@@ -443,17 +542,38 @@ def main(argv=None, runtime=None):
     hb = [agg[k] for k in ("pool_assemble", "roi_replay") if k in agg]
     if hb:
         nb, sec = sum(a[1] for a in hb), sum(a[2] for a in hb)
-        line.setdefault("roofline_other", {})["RoI feature-replay pass (pool_assemble + roi_replay_inplace)"] = {
-            "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_region": nb / (args.steps * B),
-            "us_per_region": sec / (args.steps * B) * 1e6, "launches": sum(a[3] for a in hb)}
+        hbm_entry("RoI feature-replay pass (pool_assemble + roi_replay_inplace)", nb, sec, sum(a[3] for a in hb), sec / elapsed,
+                  algorithmic_bytes_per_region=nb / (args.steps * B), us_per_region=sec / (args.steps * B) * 1e6)
     if "roi_replay" in agg:
         fl, nb, sec, cnt = agg["roi_replay"]
-        line.setdefault("roofline_other", {})["roi_replay_inplace_kernel alone (one launch per 16-region chunk; ~1 MB per "
-                                              "crop token: launch / latency bound)"] = {
-            "bound": "hbm", "achieved": nb / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": nb / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": nb / cnt, "avg_launch_us": sec / cnt * 1e6,
-            "launches": cnt}
+        hbm_entry("roi_replay_inplace_kernel alone (one launch per prefill pass; ~1 MB per crop token: launch / latency bound)",
+                  nb, sec, cnt, sec / elapsed, bytes_per_launch=nb / cnt)
+    # decode kernels (inside the hipGraph during the timed region): per-step time from the eager probe x (new_tokens - 1) steps
+    if pagg:
+        t_ = cfg.mllm_config.text_config
+        nsteps_probe = args.decode_probe_steps
+        dec_steps = args.new_tokens - 1
+        probe_note = (f"timed on {nsteps_probe} eager decode steps of the same batch after the timed region (inside it these "
+                      f"kernels replay from the hipGraph); time_share_of_step = per-step time x {dec_steps} steps / step time")
+        if "decode:attn_decode" in pagg:
+            fl, nb, sec, cnt = pagg["decode:attn_decode"]
+            nb = cnt * B * t_.num_key_value_heads * (S + 1 + nsteps_probe / 2.0) * t_.head_dim * 4.0    # K + V rows of every sequence
+            hbm_entry("decode_attn_lds_kernel, decode steps (KV cache streamed once per step and layer)", nb, sec, cnt,
+                      sec / nsteps_probe * dec_steps / step_s, us_per_decode_step=sec / nsteps_probe * 1e6, note=probe_note)
+        if "decode:gemm_skinny_bf16" in pagg:
+            fl, nb, sec, cnt = pagg["decode:gemm_skinny_bf16"]
+            hbm_entry("skinny_mt_bf16_kernel, decode steps (qkv / o / gate-up / down GEMVs of every layer + lm_head: weights "
+                      "streamed once per step for all B rows)", nb, sec, cnt, sec / nsteps_probe * dec_steps / step_s,
+                      us_per_decode_step=sec / nsteps_probe * 1e6, weight_bytes_per_decode_step=nb / nsteps_probe, note=probe_note)
+        if "decode:splitk_reduce" in pagg:
+            fl, nb, sec, cnt = pagg["decode:splitk_reduce"]
+            hbm_entry("splitk_res_rms_kernel, decode steps (split-K reduce + residual (+ final RMSNorm))", nb, sec, cnt,
+                      sec / nsteps_probe * dec_steps / step_s, us_per_decode_step=sec / nsteps_probe * 1e6, note=probe_note)
+        tot = sum(a[2] for a in pagg.values())
+        line["decode_step_probe"] = {"eager_us_per_step_sum_of_kernels": tot / nsteps_probe * 1e6, "steps": nsteps_probe,
+                                     "kernels_per_step": sum(a[3] for a in pagg.values()) / nsteps_probe}
+    covered = sum(v.get("time_share_of_step", 0.0) for k, v in other.items() if not k.startswith("roi_replay_inplace_kernel alone"))
+    line["time_share_covered"] = (roof["time_share_of_step"] if roof else 0.0) + covered
     if not args.no_cpu_baseline and world == 1 and args.workload == "video":
         line["cpu_baseline"] = {"value": None, "note": "the CPU oracle leg is wired for the image workloads (run "
                                                        "--workload single for the headline line's baseline)"}

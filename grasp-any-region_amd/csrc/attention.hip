@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     // Q fragments (B operand): Q[q0 + l31][16 kd + 8h .. +8]
     bf16x8 qf[NKD];
     {
-        const int qrow = min(q0 + l31, q_pad - 1);
+        const int qrow = min(q0 + l31, q_len - 1);        // rows >= q_len are never stored: a pointer into a larger Q stays in bounds
 #pragma unroll
         for (int kd = 0; kd < NKD; ++kd)
             qf[kd] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * HD + kd * 16 + h * 8);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     const float* Vp = Vt + (((int64_t)b * Hkv + kvh) * HD) * (int64_t)kv_stride;       // same slab offset in either layout
     float qf[HD / 2];
     {
-        const int qrow = min(q0 + l31, q_pad - 1);
+        const int qrow = min(q0 + l31, q_len - 1);        // rows >= q_len are never stored: a pointer into a larger Q stays in bounds
 #pragma unroll
         for (int k = 0; k < HD / 2; ++k) qf[k] = Qp[(int64_t)qrow * HD + 2 * k + h];
     }

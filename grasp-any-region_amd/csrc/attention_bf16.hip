@@ -39,6 +39,9 @@ template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 
 // consecutive kv of one d that the MFMA fragment wants. The 16-byte chunks of a V row are XOR-ed with 4 ((kv >> 1) & 1):
 // the four rows of a block (128 B apart) then cover all 64 banks exactly once for a 32-lane half.
 typedef short tr4_t __attribute__((ext_vector_type(4)));
+#ifndef ATTN_PK_SUM        /* n > 0: row sums of P in n packed-fp32 partial chains (v_pk_add_f32) instead of 32 scalar adds per tile */
+#define ATTN_PK_SUM 0
+#endif
 #ifndef ATTN_MFMA_ROWSUM   /* 1: row sums of P on the matrix pipe (ones x P), instead of 32 VALU adds per tile and lane */
 #define ATTN_MFMA_ROWSUM 0
 #endif
@@ -253,14 +256,23 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             // p = exp2(s - m_sub) (NEGM: s already carries -m), row sum, bf16 pack
             auto exp_pack = [&](float m_sub) {
                 ps = 0.f;
+#if ATTN_PK_SUM
+                f32v2_t ps2[ATTN_PK_SUM] = {};          // row sums as packed fp32 adds (v_pk_add_f32: two adds per instruction)
+#endif
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
                     float p[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_sub);
+#if !ATTN_PK_SUM
                         if (!ATTN_MFMA_ROWSUM) ps += p[r];
+#endif
                     }
+#if ATTN_PK_SUM
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) ps2[(r >> 1) % ATTN_PK_SUM] += f32v2_t{p[r], p[r + 1]};
+#endif
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         u32x4 w;
@@ -271,6 +283,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                         pf[blk][tt] = __builtin_bit_cast(bf16x8, w);
                     }
                 }
+#if ATTN_PK_SUM
+                {
+                    f32v2_t t2 = ps2[0];
+#pragma unroll
+                    for (int i = 1; i < ATTN_PK_SUM; ++i) t2 += ps2[i];
+                    ps = t2[0] + t2[1];
+                }
+#endif
                 if (ATTN_MFMA_ROWSUM) {
                     // ones[32 x 16] x P[16 kv x 32 q], four k-steps: every register of the result is the COMPLETE row sum of
                     // this lane's query column (both kv halves) of the bf16-rounded P — what the PV product divides by

@@ -48,7 +48,15 @@ struct decode_qkv_args {
     const float* cs;
     const float* sn;            // [max_pos, HD / 2] f32
     float q_scale;
+    int strip;                  // q / k head columns of `raw` in the fused RoPE epilogue's strip order (head_dim 128: dims
+                                // [0..31, 64..95, 32..63, 96..127]; include/gar_hip.h GAR_EPI_QKV_ROPE_LLM) — the folded qkv weight's
 };
+template <int HD>
+__device__ __forceinline__ int strip_col_d(int d0, bool strip) {
+    if (HD != 128 || !strip) return d0;
+    const int blk = d0 >> 5;
+    return blk == 1 ? d0 + 32 : (blk == 2 ? d0 - 32 : d0);
+}
 
 template <int HD>
 __device__ __forceinline__ void load_q_rotated(bf16x8 (&qf)[HD / 16], const decode_qkv_args& fa, int b, int Hq, int Hkv, int head,
@@ -59,8 +67,8 @@ __device__ __forceinline__ void load_q_rotated(bf16x8 (&qf)[HD / 16], const deco
     for (int kd = 0; kd < NKD / 2; ++kd) {
         const int off = kd * 16 + h * 8;
         float x1[8], x2[8], c[8], sv[8];
-        ld8(rq + off, x1);
-        ld8(rq + HALF + off, x2);
+        ld8(rq + strip_col_d<HD>(off, fa.strip), x1);
+        ld8(rq + strip_col_d<HD>(HALF + off, fa.strip), x2);
         ld8(fa.cs + (int64_t)rp * HALF + off, c);
         ld8(fa.sn + (int64_t)rp * HALF + off, sv);
 #pragma unroll
@@ -86,8 +94,8 @@ __device__ __forceinline__ void append_new_kv(const decode_qkv_args& fa, bf16_t*
         const int i8 = lane * 8;
         const bf16_t* rk = row + (Hq + kvh) * HD;
         float x1[8], x2[8], c[8], sv[8];
-        ld8(rk + i8, x1);
-        ld8(rk + HALF + i8, x2);
+        ld8(rk + strip_col_d<HD>(i8, fa.strip), x1);
+        ld8(rk + strip_col_d<HD>(HALF + i8, fa.strip), x2);
         ld8(fa.cs + (int64_t)rp * HALF + i8, c);
         ld8(fa.sn + (int64_t)rp * HALF + i8, sv);
 #pragma unroll
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
                                                                  float* __restrict__ part,
                                                                  int Hq, int Hkv, int kv_stride,
                                                                  const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
-                                                                 bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
+                                                                 bf16_t* __restrict__ O_direct, const decode_qkv_args fa, int64_t q_stride) {
     constexpr int HD = 64, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 8 KiB | V 8 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 16384);
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
         load_q_rotated<HD>(qf, fa, b, Hq, Hkv, kvh * G + min(l31, G - 1), l31 < G, h, rp);
     } else {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
+        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * q_stride;
 #pragma unroll
         for (int kd = 0; kd < NKD; ++kd)
             qf[kd] = l31 < G ? *reinterpret_cast<const bf16x8*>(qp + kd * 16 + h * 8) : z;
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
                                                                     float* __restrict__ part,
                                                                     int Hq, int Hkv, int kv_stride,
                                                                     const int32_t* __restrict__ kv_len_dev, const int32_t* __restrict__ kv_start,
-                                                                    bf16_t* __restrict__ O_direct, const decode_qkv_args fa) {
+                                                                    bf16_t* __restrict__ O_direct, const decode_qkv_args fa, int64_t q_stride) {
     constexpr int HD = 128, NKD = HD / 16, NDB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4 waves][K 16 KiB | V 16 KiB] then red
     float (*red)[8][HD + 2] = reinterpret_cast<float (*)[8][HD + 2]>(smem + 4 * 32768);
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
         load_q_rotated<HD>(qf, fa, b, Hq, Hkv, kvh * G + min(l31, G - 1), l31 < G, h, rp);
     } else {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * HD;
+        const bf16_t* qp = Q + ((int64_t)b * Hq + kvh * G + min(l31, G - 1)) * q_stride;
 #pragma unroll
         for (int kd = 0; kd < NKD; ++kd)
             qf[kd] = l31 < G ? *reinterpret_cast<const bf16x8*>(qp + kd * 16 + h * 8) : z;
@@ -556,7 +564,7 @@ extern "C" int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max
     return (int64_t)B * Hq * max_splits * (hd + 2) * 4;
 }
 
-static int launch_decode(const void* q, void* Kc, void* Vc, void* O, int B, int Hq, int Hkv, int hd, int Smax,
+static int launch_decode(const void* q, int64_t q_stride, void* Kc, void* Vc, void* O, int B, int Hq, int Hkv, int hd, int Smax,
                          const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits, void* workspace,
                          const decode_qkv_args& fa, gar_stream_t stream) {
     GAR_CHECK_ARG(workspace && max_splits > 0 && max_splits <= 64, "attention_decode: workspace / max_splits (1..64)");
@@ -571,24 +579,24 @@ static int launch_decode(const void* q, void* Kc, void* Vc, void* O, int B, int 
     if (hd == 64) {
         constexpr int lds = 4 * 16384 + 4 * 8 * (64 + 2) * 4;
         static gar_once_per_device attr_once;
-        if (attr_once.first()) {
+        attr_once.run([&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        }
+        });
         hipLaunchKernelGGL(decode_attn_lds_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)Kc,
-                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
+                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa, q_stride);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<64>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
     } else {
         constexpr int lds = 4 * 32768 + 4 * 8 * (128 + 2) * 4;
         static gar_once_per_device attr_once;
-        if (attr_once.first()) {
+        attr_once.run([&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_lds128_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        }
+        });
         hipLaunchKernelGGL(decode_attn_lds128_kernel, grid, dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)Kc,
-                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa);
+                           (bf16_t*)Vc, (float*)workspace, Hq, Hkv, Smax, kv_len_dev, kv_start, direct, fa, q_stride);
         if (!direct)
             hipLaunchKernelGGL((decode_combine_kernel<128>), dim3(Hq, B), dim3(64), 0, s, (const float*)workspace,
                                (bf16_t*)O, Hq, Hkv, max_splits);
@@ -597,28 +605,31 @@ static int launch_decode(const void* q, void* Kc, void* Vc, void* O, int B, int 
     return GAR_OK;
 }
 
-extern "C" int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq,
-                                    int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
+extern "C" int gar_attention_decode(int dtype, const void* q, int64_t q_stride, const void* Kc, const void* Vc, void* O, int B,
+                                    int Hq, int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start,
                                     int max_splits, void* workspace, gar_stream_t stream) {
     GAR_CHECK_ARG(q && Kc && Vc && O && kv_len_dev, "attention_decode: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode: Hq/Hkv must be <= 8");
     GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode: Smax must be a multiple of 64");
     GAR_CHECK_ARG(hd == 64 || hd == 128, "attention_decode: head_dim %d not built (64, 128)", hd);
-    if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split
-        return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, 1, 0, Smax, 0, kv_len_dev, kv_start, 0, stream);
+    if (q_stride <= 0) q_stride = hd;
+    GAR_CHECK_ARG(q_stride % hd == 0 && ((uintptr_t)q & 15) == 0, "attention_decode: q_stride must be a multiple of head_dim, q 16-byte aligned");
+    if (dtype == GAR_F32)   // parity mode: the prefill kernel with q_len = 1 (exact-f32 MFMA), no split; (b, head) rows q_stride apart
+        return gar_attention_vrow(dtype, q, Kc, Vc, O, B, Hq, Hkv, hd, 1, (int)(q_stride / hd), 0, Smax, 0, kv_len_dev, kv_start, 0,
+                                  stream);
     GAR_CHECK_ARG(dtype == GAR_BF16, "attention_decode: bad dtype");
-    const decode_qkv_args none = {nullptr, nullptr, nullptr, 0.f};
+    const decode_qkv_args none = {nullptr, nullptr, nullptr, 0.f, 0};
     // (the plain form only reads the caches)
-    return launch_decode(q, const_cast<void*>(Kc), const_cast<void*>(Vc), O, B, Hq, Hkv, hd, Smax, kv_len_dev, kv_start, max_splits,
-                         workspace, none, stream);
+    return launch_decode(q, q_stride, const_cast<void*>(Kc), const_cast<void*>(Vc), O, B, Hq, Hkv, hd, Smax, kv_len_dev, kv_start,
+                         max_splits, workspace, none, stream);
 }
 
 // gar_llm_qkv_post (S = 1) + gar_attention_decode in ONE launch (bf16): see decode_qkv_args. GAR_ERR_UNSUPPORTED (nothing
 // launched) in parity mode: the caller keeps the two calls.
 extern "C" int gar_attention_decode_qkv(int dtype, const void* qkv, const float* cos, const float* sin, void* Kc, void* Vc,
                                         void* O, int B, int Hq, int Hkv, int hd, int Smax, const int32_t* pos_dev,
-                                        const int32_t* left_pad, float q_scale, int max_splits, void* workspace,
-                                        gar_stream_t stream) {
+                                        const int32_t* left_pad, float q_scale, int qk_strip_order, int max_splits,
+                                        void* workspace, gar_stream_t stream) {
     GAR_CHECK_ARG(qkv && cos && sin && Kc && Vc && O && pos_dev, "attention_decode_qkv: null pointer");
     GAR_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "attention_decode_qkv: Hq/Hkv must be <= 8");
     GAR_CHECK_ARG(Smax % 64 == 0, "attention_decode_qkv: Smax must be a multiple of 64");
@@ -628,6 +639,6 @@ extern "C" int gar_attention_decode_qkv(int dtype, const void* qkv, const float*
         gar_set_error("attention_decode_qkv: bf16 only (parity mode runs gar_llm_qkv_post + gar_attention_decode)");
         return GAR_ERR_UNSUPPORTED;
     }
-    const decode_qkv_args fa = {(const bf16_t*)qkv, cos, sin, q_scale};
-    return launch_decode(nullptr, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev, left_pad, max_splits, workspace, fa, stream);
+    const decode_qkv_args fa = {(const bf16_t*)qkv, cos, sin, q_scale, qk_strip_order ? 1 : 0};
+    return launch_decode(nullptr, hd, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev, left_pad, max_splits, workspace, fa, stream);
 }

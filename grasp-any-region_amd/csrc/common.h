@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/gar_hip.h"
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
@@ -119,13 +122,23 @@ static inline int gar_current_device() {
     return d;
 }
 struct gar_once_per_device {
-    bool done[GAR_MAX_DEVICES] = {};
-    bool first() {
+    // run(f): f() once per device, and no caller returns before the f() of its device has COMPLETED — a second host thread
+    // driving the same device must not launch a kernel that needs the attribute f sets (dynamic LDS above 64 KiB) before it is
+    // set (the flag used to be raised before the caller ran hipFuncSetAttribute)
+    std::atomic<bool> done[GAR_MAX_DEVICES] = {};
+    std::mutex mu;
+    template <class F>
+    void run(F&& f) {
         const int d = gar_current_device();
-        if (d < 0 || d >= GAR_MAX_DEVICES) return true;
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        if (d < 0 || d >= GAR_MAX_DEVICES) {
+            f();
+            return;
+        }
+        if (done[d].load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[d].load(std::memory_order_relaxed)) return;
+        f();
+        done[d].store(true, std::memory_order_release);
     }
 };
 static inline int gar_num_cus() {          // of the current device

@@ -15,6 +15,7 @@
 #include "gemm_epilogue.h"
 
 bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s);   // gemm_pp.hip
+bool gar_gemm_pp_takes(const gar_gemm_params& p);                // gemm_pp.hip: the predicate alone
 bool gar_skinny_bf16_try(const gar_gemm_params& p, hipStream_t s);   // gemm_skinny.hip
 
 // ===============================================================================================================
@@ -324,6 +325,18 @@ static int launch(int dtype, const gar_gemm_params& p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(tmn * tnn), dim3(256), 0, s, p, tmn, tnn);
     }
     return GAR_OK;
+}
+
+// 1 when gar_gemm would run this problem on the persistent 256 x 256 bf16 tile GEMM (csrc/gemm_pp.hip) — the kernel whose
+// epilogues carry the folded norms (row_scale / row_stats) and the fused qkv forms; 0 otherwise. Nothing is launched.
+extern "C" int gar_gemm_tile_takes(int dtype, const gar_gemm_params* pp) {
+    if (!pp || dtype != GAR_BF16 || pp->M <= 0 || pp->N <= 0 || pp->K <= 0 || pp->K % 64 != 0 || pp->split_k > 1 || pp->norm_w ||
+        pp->norm_folded)
+        return 0;
+    if (pp->M <= 64 && !(pp->row_scale || pp->row_stats) && pp->epilogue != GAR_EPI_QKV_ROPE && pp->epilogue != GAR_EPI_QKV_ROPE_LLM &&
+        pp->epilogue != GAR_EPI_PATCH_POS && pp->epilogue != GAR_EPI_BIAS_GELU && pp->epilogue != GAR_EPI_BIAS_SCALE_RES)
+        return 0;                                                   // the skinny kernel is asked first for these
+    return gar_gemm_pp_takes(*pp) ? 1 : 0;
 }
 
 extern "C" int gar_gemm(int dtype, const gar_gemm_params* pp, gar_stream_t stream) {

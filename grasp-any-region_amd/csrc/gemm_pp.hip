@@ -1085,10 +1085,10 @@ template <int EPI>
 static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hipStream_t s) {
     constexpr int LDS = 2 * PSTAGE + (EPI == GAR_EPI_BIAS_GELU ? GELU_LUT_BYTES : 0);
     static gar_once_per_device attr_once;
-    if (attr_once.first()) {
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(min(pm * pn, num_cus)), dim3(512), LDS, s, p, pm, pn,
                        gar_gather_args{});                                                                      // persistent
 }
@@ -1139,19 +1139,20 @@ extern "C" int gar_patch_embed(int dtype, const void* pixel, const void* maskbin
     ga.bytes = (unsigned)bytes;
     constexpr int LDS = 2 * PSTAGE;
     static gar_once_per_device attr_once;
-    if (attr_once.first()) {
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
+    });
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<GAR_EPI_PATCH_POS, true>), dim3(min(pm * pn, pp_num_cus())), dim3(512), LDS,
                        (hipStream_t)stream, p, pm, pn, ga);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }
 
-// returns true if the problem was taken (large bf16 GEMMs); small ones stay on the 128x128 kernel
-bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
-    const int num_cus = pp_num_cus();
+// true when the persistent tile GEMM is built for the problem (large bf16 GEMMs; small ones stay on the 128x128 kernel).
+// Exported through gar_gemm_tile_takes(): the host asks THIS predicate before it plans a pass around the folded-norm
+// epilogues (row_scale / row_stats), which only this kernel has — one copy of the conditions.
+bool gar_gemm_pp_takes(const gar_gemm_params& p) {
     const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
     if (pm * pn < 128 || p.N < 256 || (p.N % 8) != 0) return false;
     // the row-coalesced epilogue moves 16-byte vectors of C / residual / bias / gamma / pos
@@ -1170,6 +1171,14 @@ bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
                          e_ == GAR_EPI_QKV_ROPE_LLM || (e_ == GAR_EPI_QKV_ROPE && !p.qkv_cos && p.qkv_v)))
         return false;
     if (p.row_stats && !(e_ == GAR_EPI_RES || e_ == GAR_EPI_BIAS_SCALE_RES)) return false;
+    return e_ >= GAR_EPI_NONE && e_ <= GAR_EPI_QKV_ROPE_LLM;
+}
+
+// returns true if the problem was taken
+bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
+    if (!gar_gemm_pp_takes(p)) return false;
+    const int num_cus = pp_num_cus();
+    const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
     switch (p.epilogue) {
         case GAR_EPI_NONE: launch_pp<GAR_EPI_NONE>(p, pm, pn, num_cus, s); break;
         case GAR_EPI_BIAS: launch_pp<GAR_EPI_BIAS>(p, pm, pn, num_cus, s); break;

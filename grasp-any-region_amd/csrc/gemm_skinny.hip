@@ -331,7 +331,7 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
                         ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
     constexpr int MAXLDS = 139264;
     static gar_once_per_device attr_once;
-    if (attr_once.first()) {
+    attr_once.run([&] {
         if constexpr (NT <= 2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
@@ -346,7 +346,7 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-    }
+    });
     // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, LDS (merge buffer, and the
     // per-wave staging regions it aliases) <= 136 KiB
     auto lds_for = [&](int w) {

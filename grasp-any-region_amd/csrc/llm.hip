@@ -6,6 +6,17 @@
 //   argmax         greedy sampling with first-index tie break; writes into the device-side token matrix
 #include "common.h"
 
+// Column of natural dim d0 (first element of an 8-wide slice) inside a q / k head whose rows of W — and therefore whose columns
+// of the qkv GEMM output — are in the fused RoPE epilogue's strip order (include/gar_hip.h, GAR_EPI_QKV_ROPE_LLM: the only
+// bf16 copy of the Llama qkv weight is the folded one in that order): head_dim 128 keeps dims [0..31, 64..95, 32..63, 96..127],
+// head_dim 64 the natural order.
+template <int HD>
+__device__ __forceinline__ int strip_col(int d0, bool strip) {
+    if (HD != 128 || !strip) return d0;
+    const int blk = d0 >> 5;
+    return blk == 1 ? d0 + 32 : (blk == 2 ? d0 - 32 : d0);
+}
+
 // block = (batch b, 64-position chunk); loops over all heads of q, k, v.
 // thread (token nl = tid/ (HD/16), i8 = 8-wide slice of the FIRST half): rotates (x[i], x[i+HD/2]) pairs of the q / k heads;
 // the v heads go through the same loop unrotated (cos = 1, sin = 0) into the row-major V cache.
@@ -15,7 +26,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
                                                            T* __restrict__ Kc, T* __restrict__ Vc, int S, int Spad,
                                                            int Hq, int Hkv, int Smax, int pos0,
                                                            const int32_t* __restrict__ pos_dev,
-                                                           const int32_t* __restrict__ left_pad, float q_scale) {
+                                                           const int32_t* __restrict__ left_pad, float q_scale, int strip) {
     constexpr int HALF = HD / 2;
     constexpr int LPT = HALF / 8;               // lanes per token (4 for hd 64, 8 for hd 128)
     constexpr int TPP = 256 / LPT;              // tokens per pass (64 / 32)
@@ -49,8 +60,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(const T* __restrict__
                 const int head = head0 + u;
                 if (s < S && head < nh) {
                     const T* row = qkv + ((int64_t)b * S + s) * W + head * HD;
-                    ld8(row + i8, x1[u]);
-                    ld8(row + HALF + i8, x2[u]);
+                    const bool so = strip && head < Hq + Hkv;          // v heads keep the natural order
+                    ld8(row + strip_col<HD>(i8, so), x1[u]);
+                    ld8(row + strip_col<HD>(HALF + i8, so), x2[u]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x1[u][e] = x2[u][e] = 0.f;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
                                                                   T* __restrict__ Kc, T* __restrict__ Vc, int B, int Spad,
                                                                   int Hq, int Hkv, int Smax, int pos0,
                                                                   const int32_t* __restrict__ pos_dev,
-                                                                  const int32_t* __restrict__ left_pad, float q_scale) {
+                                                                  const int32_t* __restrict__ left_pad, float q_scale, int strip) {
     constexpr int HALF = HD / 2, LPH = HALF / 8;
     const int nh = Hq + 2 * Hkv;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,8 +111,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
     const int p0 = pos_dev ? pos_dev[0] : pos0;
     const T* row = qkv + (int64_t)b * nh * HD + head * HD;
     float x1[8], x2[8];
-    ld8(row + i8, x1);
-    ld8(row + HALF + i8, x2);
+    const bool so = strip && head < Hq + Hkv;
+    ld8(row + strip_col<HD>(i8, so), x1);
+    ld8(row + strip_col<HD>(HALF + i8, so), x2);
     if (head < Hq + Hkv) {
         const int rp = max(p0 - (left_pad ? left_pad[b] : 0), 0);          // RoPE position; the cache row stays p0
         const float* cp = cs + (int64_t)rp * HALF + i8;
@@ -121,8 +134,10 @@ __global__ __launch_bounds__(256) void llm_qkv_post_decode_kernel(const T* __res
 
 extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, const float* sn, void* Q, void* Kc,
                                 void* Vc, int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0,
-                                const int32_t* pos_dev, const int32_t* left_pad, float q_scale, gar_stream_t stream) {
+                                const int32_t* pos_dev, const int32_t* left_pad, float q_scale, int qk_strip_order,
+                                gar_stream_t stream) {
     GAR_CHECK_ARG(qkv && cs && sn && Q && Kc && Vc, "llm_qkv_post: null pointer");
+    const int strip = qk_strip_order ? 1 : 0;
     GAR_CHECK_ARG(B > 0 && S > 0 && Spad >= S && Smax % 64 == 0, "llm_qkv_post: bad shape");
     GAR_CHECK_ARG(pos_dev || pos0 + S <= Smax, "llm_qkv_post: cache overflow %d+%d > %d", pos0, S, Smax);
     GAR_CHECK_ARG(hd == 64 || hd == 128, "llm_qkv_post: head_dim %d not built (64, 128)", hd);
@@ -132,7 +147,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
         dim3 g1((total + 255) / 256), b1(256);
 #define LAUNCH_LQD(TT, HD_)                                                                                         \
     hipLaunchKernelGGL((llm_qkv_post_decode_kernel<TT, HD_>), g1, b1, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc, \
-                       (TT*)Vc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
+                       (TT*)Vc, B, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale, strip)
         if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQD(bf16_t, 64); else LAUNCH_LQD(bf16_t, 128); }
         else { if (hd == 64) LAUNCH_LQD(float, 64); else LAUNCH_LQD(float, 128); }
 #undef LAUNCH_LQD
@@ -142,7 +157,7 @@ extern "C" int gar_llm_qkv_post(int dtype, const void* qkv, const float* cs, con
     dim3 grid(B * ((Spad + 63) / 64)), block(256);
 #define LAUNCH_LQP(TT, HD_)                                                                                       \
     hipLaunchKernelGGL((llm_qkv_post_kernel<TT, HD_>), grid, block, 0, s, (const TT*)qkv, cs, sn, (TT*)Q, (TT*)Kc,  \
-                       (TT*)Vc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale)
+                       (TT*)Vc, S, Spad, Hq, Hkv, Smax, pos0, pos_dev, left_pad, q_scale, strip)
     if (dtype == GAR_BF16) { if (hd == 64) LAUNCH_LQP(bf16_t, 64); else LAUNCH_LQP(bf16_t, 128); }
     else { if (hd == 64) LAUNCH_LQP(float, 64); else LAUNCH_LQP(float, 128); }
 #undef LAUNCH_LQP

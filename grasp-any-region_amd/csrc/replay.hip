@@ -89,7 +89,8 @@ extern "C" int gar_placeholder_scan(const int64_t* input_ids, int B, int S, int6
 __global__ __launch_bounds__(256) void input_check_kernel(const int64_t* __restrict__ ids, int S, int64_t vocab,
                                                           const int32_t* __restrict__ counts, int n_rows,
                                                           const int32_t* __restrict__ spans, int n_crop, int span_len,
-                                                          const int32_t* __restrict__ has_box, int32_t* __restrict__ flags) {
+                                                          const int32_t* __restrict__ has_box, int32_t* __restrict__ flags,
+                                                          const uint8_t* __restrict__ attn_mask) {
     const int b = blockIdx.x;
     int bad = 0;
     const int64_t* row = ids + (int64_t)b * S;
@@ -97,8 +98,19 @@ __global__ __launch_bounds__(256) void input_check_kernel(const int64_t* __restr
         const int64_t v = row[s];
         if (v < 0 || v >= vocab) bad |= 8;
     }
-    if (threadIdx.x == 0 && counts[b] != n_rows) bad |= 1;
-    if ((int)threadIdx.x < n_crop) {
+    if (attn_mask) {
+        // a generation mask has to be LEFT-padded, 0...01...1 (HF's convention; generate() derives left_pad from its zero
+        // count): a 1 followed by a 0, or a 0 in the last column, is a row that would be continued after its padding
+        const uint8_t* mr = attn_mask + (int64_t)b * S;
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const bool cur = mr[s] != 0;
+            const bool nxt = s + 1 < S ? mr[s + 1] != 0 : true;
+            if (cur && !nxt) bad |= 16;
+            if (s == S - 1 && !cur) bad |= 16;
+        }
+    }
+    if (counts && threadIdx.x == 0 && counts[b] != n_rows) bad |= 1;
+    if (spans && has_box && (int)threadIdx.x < n_crop) {
         const int lo = spans[((int64_t)b * n_crop + threadIdx.x) * 2], hi = spans[((int64_t)b * n_crop + threadIdx.x) * 2 + 1];
         const bool present = hi >= 0, box = (has_box[b] >> threadIdx.x) & 1;
         if (present && box && hi - lo + 1 != span_len) bad |= 2;
@@ -109,11 +121,12 @@ __global__ __launch_bounds__(256) void input_check_kernel(const int64_t* __restr
 
 extern "C" int gar_input_check(const int64_t* input_ids, int B, int S, int64_t vocab, const int32_t* counts, int n_rows,
                                const int32_t* spans, int n_crop, int span_len, const int32_t* has_box, int32_t* flags,
-                               gar_stream_t stream) {
-    GAR_CHECK_ARG(input_ids && counts && spans && has_box && flags && B > 0 && S > 0 && n_crop >= 0 && n_crop <= 8,
+                               const uint8_t* attn_mask, gar_stream_t stream) {
+    // counts / (spans, has_box) NULL: that group of checks is skipped (a text-only prompt has no placeholders to count)
+    GAR_CHECK_ARG(input_ids && flags && B > 0 && S > 0 && n_crop >= 0 && n_crop <= 8 && (!spans == !has_box),
                   "input_check: bad args");
     hipLaunchKernelGGL(input_check_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, input_ids, S, vocab, counts, n_rows,
-                       spans, n_crop, span_len, has_box, flags);
+                       spans, n_crop, span_len, has_box, flags, attn_mask);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }

@@ -122,6 +122,47 @@ extern "C" int gar_cls_pos_fill(int dtype, void* x, const void* cls, const void*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// x[t, token_offset + p, :] += add[t, p, :] — `x = x + mask_embeds.flatten(2).transpose(1, 2)` of the reference's
+// custom_forward_features (modeling_perception_lm.py:195-196) for callers that hand the mask-embedding conv's output to
+// mllm.get_image_features themselves (generate() never needs it: its mask conv is K columns of the patch-embed GEMM).
+// One rounding in the tensor's dtype, like the reference's add.
+template <typename T>
+__global__ __launch_bounds__(256) void tokens_add_kernel(T* __restrict__ x, const T* __restrict__ add, int64_t n8, int tokens_in,
+                                                         int tokens_out, int token_offset, int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int64_t e = i * 8;                                  // element of add [T, tokens_in, D]
+    const int d = (int)(e % D);
+    const int64_t row = e / D;
+    const int p = (int)(row % tokens_in);
+    const int64_t t = row / tokens_in;
+    T* xp = x + ((t * tokens_out + token_offset + p) * (int64_t)D + d);
+    float a[8], b[8];
+    ld8(xp, a);
+    ld8(add + e, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += b[k];
+    st8(xp, a);
+}
+
+extern "C" int gar_tokens_add(int dtype, void* x, const void* add, int T_, int tokens_in, int tokens_out, int token_offset, int D,
+                              gar_stream_t stream) {
+    GAR_CHECK_ARG(x && add && T_ > 0 && tokens_in > 0 && token_offset >= 0 && tokens_out >= tokens_in + token_offset && D > 0 &&
+                      D % 8 == 0, "tokens_add: bad args");
+    const int64_t n8 = (int64_t)T_ * tokens_in * D / 8;
+    dim3 grid((unsigned)((n8 + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((tokens_add_kernel<bf16_t>), grid, block, 0, s, (bf16_t*)x, (const bf16_t*)add, n8, tokens_in, tokens_out,
+                           token_offset, D);
+    else
+        hipLaunchKernelGGL((tokens_add_kernel<float>), grid, block, 0, s, (float*)x, (const float*)add, n8, tokens_in, tokens_out,
+                           token_offset, D);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // vit_qkv_post: block = (tile t, head h, 64-token chunk); 256 threads = 32 tokens x 8 lanes x 8 elements, 2 passes.
 // V goes through LDS so Vt rows (64 consecutive tokens of one d) are written as full lines.
 // ---------------------------------------------------------------------------------------------------------------

@@ -45,9 +45,12 @@ def base_parser(description, default_model, default_cache, default_images):
     ap.add_argument("--output_dir", default=None, help="default: the reference's model_outputs directory")
     ap.add_argument("--limit", type=int, default=0, help="only the first N items (smoke runs)")
     ap.add_argument("--host_preprocessing", action="store_true")
-    ap.add_argument("--batch_size", type=int, default=8,
-                    help="items per generate call: prompts of different lengths go in as ONE left-padded batch with an "
-                         "attention_mask (items with the same tile count are grouped); 1 = one item per call like the reference")
+    ap.add_argument("--batch_size", type=int, default=1,
+                    help="items per generate call. 1 (default) = one item per call like the reference's loops. n > 1: prompts of "
+                         "different lengths go in as ONE left-padded batch with an attention_mask (items with the same tile count "
+                         "are grouped) — mathematically the same function, but in bf16 the batch size selects kernels (skinny vs "
+                         "tile GEMM, split-K, folded norms), so a caption can differ from the per-item run at near-tied steps; the "
+                         "mode a file was produced in is recorded next to it (<cache>.meta.json)")
     ap.add_argument("--synthetic_weights", action="store_true")
     return ap
 
@@ -71,7 +74,27 @@ def load(args):
         processor = GARProcessor.from_pretrained(args.model_name_or_path, model.config, args.max_num_tiles)
     if not args.host_preprocessing:
         processor.use_gpu_preprocessing(device, dtype)
+    args._model = model                     # write_run_meta reads the fused-path switches off it
     return model.eval(), processor, dtype, device, rank, world
+
+
+def write_run_meta(path, args, model):
+    """<outputs>.meta.json beside a loop's output file: how the captions were produced (the output file keeps the reference's
+    record format). In bf16, batch size and pass sizes select kernels, so two runs of the same items can differ at near-tied
+    greedy steps ("Batching and caption-level drift")."""
+    meta = {"batch_size": int(getattr(args, "batch_size", 1) or 1), "data_type": args.data_type,
+            "max_num_tiles": args.max_num_tiles, "max_new_tokens": args.max_new_tokens,
+            "synthetic_weights": bool(args.synthetic_weights), "host_preprocessing": bool(args.host_preprocessing),
+            "fused_paths": {k: bool(getattr(model, k)) for k in ("FOLD_NORMS", "LLM_QKV_EPILOGUE", "DECODE_GU_NORM_FOLDED",
+                                                                 "DECODE_ATTN_TAKES_QKV", "VIT_CLS_KEY_FOLD",
+                                                                 "PRUNE_LAST_PREFILL_LAYER") if hasattr(model, k)},
+            "abi_version": hip_abi_version()}
+    json.dump(meta, open(os.path.splitext(path)[0] + ".meta.json", "w"), indent=2)
+
+
+def hip_abi_version():
+    from . import hip
+    return hip.ABI_VERSION
 
 
 def _generate(model, processor, sample, args, skip_special_tokens):
@@ -215,6 +238,7 @@ def run_gar_bench(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{cache}.json")
     json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    write_run_meta(path, args, args._model)
     if args.mode == "vqa":      # exact-match accuracy per category and overall (:185-203)
         for cat in sorted(set(x["type"] for x in outputs)):
             res = [x for x in outputs if x["type"] == cat]
@@ -258,6 +282,7 @@ def run_dlc_bench(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{args.cache_name}.json")
     json.dump({k: v for k, v in outputs}, open(path, "w"), indent=4, ensure_ascii=False)
+    write_run_meta(path, args, args._model)
     print(f"Cache name: {args.cache_name}")
     return path
 
@@ -308,6 +333,7 @@ def run_ferret_bench(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{args.cache_name}.json")
     json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    write_run_meta(path, args, args._model)
     print(f"Cache name: {args.cache_name}")
     return path
 
@@ -337,6 +363,7 @@ def run_mdvp_bench(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{args.cache_name}.json")
     json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    write_run_meta(path, args, args._model)
     print(f"Cache name: {args.cache_name}")
     return path
 
@@ -411,5 +438,6 @@ def run_video_refer(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{args.cache_name}.json")
     json.dump(outputs, open(path, "w"), indent=4, ensure_ascii=False)
+    write_run_meta(path, args, args._model)
     print(f"Cache name: {args.cache_name}")
     return path

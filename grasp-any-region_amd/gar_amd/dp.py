@@ -93,3 +93,21 @@ def max_over_ranks(x: float, device=None) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_gather_floats(x: float, device=None) -> List[float]:
+    """every rank's value, in rank order, on every rank ([x] without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [x]
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def describe() -> dict:
+    """what the process group actually is — printed into bench.py's JSON line so that a scaling run proves its ranks."""
+    if not dist.is_initialized():
+        return {"ranks_seen": 1, "backend": None}
+    return {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}

@@ -15,7 +15,7 @@ GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
  EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GarError(RuntimeError):
@@ -43,6 +43,8 @@ SIGNATURES = {
     "gar_last_error": ([], C.c_char_p),
     "gar_check_device": ([_i], _i),
     "gar_gemm": ([_i, C.POINTER(GemmParams), _vp], _i),
+    "gar_gemm_tile_takes": ([_i, C.POINTER(GemmParams)], _i),
+    "gar_tokens_add": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_patch_im2col": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_mask_decode": ([_i, _vp, _vp, _i64, _i, _vp], _i),
     "gar_patch_embed_k": ([_i, _i], _i),
@@ -55,12 +57,12 @@ SIGNATURES = {
     "gar_splitk_residual_rmsnorm": ([_i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "gar_vit_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "gar_vit_v_transpose": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
-    "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp], _i),
+    "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp], _i),
     "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
-    "gar_attention_decode": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
-    "gar_attention_decode_qkv": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp], _i),
+    "gar_attention_decode": ([_i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "gar_attention_decode_qkv": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp], _i),
     "gar_pool2x2":([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "gar_placeholder_scan": ([_vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "gar_pool_assemble": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp], _i),
@@ -76,7 +78,7 @@ SIGNATURES = {
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),
     "gar_counter_add": ([_vp, _i, _i, _vp], _i),
-    "gar_input_check": ([_vp, _i, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "gar_input_check": ([_vp, _i, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
 }
 
 _lib = None

@@ -47,15 +47,40 @@ class GenerateOutput:
     done: Optional[object] = None
 
 
-INPUT_COUNT_MISMATCH, INPUT_SPAN_LENGTH, INPUT_MISSING_BBOX, INPUT_ID_RANGE = 1, 2, 4, 8
+INPUT_COUNT_MISMATCH, INPUT_SPAN_LENGTH, INPUT_MISSING_BBOX, INPUT_ID_RANGE, INPUT_MASK_NOT_LEFT_PADDED = 1, 2, 4, 8, 16
 
 
 def describe_input_flags(flags: int) -> str:
     names = {INPUT_COUNT_MISMATCH: "image token count != image feature rows (reference: ValueError)",
              INPUT_SPAN_LENGTH: "a crop-token span is not P*P long (the reference's splice would change the sequence length)",
              INPUT_MISSING_BBOX: "a crop token present in input_ids has no bbox (reference: KeyError)",
-             INPUT_ID_RANGE: "input_ids outside [0, vocab)"}
+             INPUT_ID_RANGE: "input_ids outside [0, vocab)",
+             INPUT_MASK_NOT_LEFT_PADDED: "attention_mask is not LEFT-padded (a row is not 0...01...1): HF generation would continue "
+                                         "such a row after its padding"}
     return "; ".join(v for k, v in names.items() if flags & k)
+
+
+# GenerationConfig fields the reference forwards to HF's generate (modeling_gar.py:418-426) that would change the tokens of a
+# greedy search and are NOT implemented here: name -> the value(s) that leave greedy search unchanged. Anything else raises
+# instead of being ignored (the reference's own callers pass max_new_tokens / do_sample=False / eos / pad only).
+_NEUTRAL_GENERATION_OPTIONS = {
+    "num_beams": (None, 1), "num_beam_groups": (None, 1), "penalty_alpha": (None, 0, 0.0), "repetition_penalty": (None, 1, 1.0),
+    "encoder_repetition_penalty": (None, 1, 1.0), "length_penalty": (None, 1, 1.0), "no_repeat_ngram_size": (None, 0),
+    "diversity_penalty": (None, 0, 0.0), "bad_words_ids": (None,), "force_words_ids": (None,), "constraints": (None,),
+    "forced_bos_token_id": (None,), "forced_eos_token_id": (None,), "suppress_tokens": (None,), "begin_suppress_tokens": (None,),
+    "sequence_bias": (None,), "min_length": (None, 0), "min_new_tokens": (None, 0), "num_return_sequences": (None, 1),
+    "prompt_lookup_num_tokens": (None,), "assistant_model": (None,),
+}
+# sampling-only knobs: without do_sample they do not touch greedy search (HF warns and ignores them) — accepted
+_SAMPLING_ONLY_OPTIONS = ("temperature", "top_k", "top_p", "min_p", "typical_p", "epsilon_cutoff", "eta_cutoff")
+
+
+def _refuse_non_greedy(get):
+    for name, neutral in _NEUTRAL_GENERATION_OPTIONS.items():
+        v = get(name)
+        if not any((v is n) or (n is not None and not isinstance(v, bool) and v == n) for n in neutral):
+            raise hip.GarError(f"generation option {name}={v!r} is not implemented (greedy search only: it would change the tokens "
+                               f"and is refused rather than ignored)")
 
 
 def _round_up(x, m):
@@ -141,13 +166,14 @@ class _MllmFacade:
         return _InputEmbeddings(self._m)
 
     def get_image_features(self, pixel_values, mask_embeds=None, global_mask_values=None, **kw):
-        """modeling_perception_lm.py:239-269. ``mask_embeds`` (the output of the reference's mask_patch_embedding conv) is
-        not an input here — the mask convolution is part of the patch-embed GEMM; pass the processor's
-        ``global_mask_values`` instead."""
-        if mask_embeds is not None:
-            raise hip.GarError("mask_embeds is not taken: the mask convolution runs inside the patch-embed GEMM; pass "
-                               "global_mask_values (the processor's mask tiles) instead")
-        return self._m.get_image_features(pixel_values, global_mask_values)
+        """modeling_perception_lm.py:239-269, the reference's signature: ``mask_embeds`` [T, C_v, g, g] is the output of
+        ``model.mask_patch_embedding`` (modeling_gar.py:326-337) and is added to the patch embeddings
+        (modeling_perception_lm.py:195-196). ``generate`` does not come through here: it hands the processor's
+        ``global_mask_values`` to the patch-embed GEMM, which carries the mask convolution as extra K columns; that form is
+        available to callers too (``global_mask_values=``; not both)."""
+        if mask_embeds is not None and global_mask_values is not None:
+            raise hip.GarError("pass either mask_embeds (the reference's form) or global_mask_values (the fused form), not both")
+        return self._m.get_image_features(pixel_values, global_mask_values, mask_embeds=mask_embeds)
 
     def get_placeholder_mask(self, input_ids, inputs_embeds, image_features=None, video_features=None):
         """(special_image_mask, special_video_mask) expanded to ``inputs_embeds``' shape, with the reference's count check
@@ -171,6 +197,26 @@ class _MllmFacade:
                                      f"{feats.numel() // feats.shape[-1]}")
                 masks.append((slot >= 0).unsqueeze(-1).expand_as(inputs_embeds))
         return masks[0], masks[1]
+
+
+class _MaskPatchEmbedding:
+    """``model.mask_patch_embedding`` of the reference (nn.Conv2d(3, C_v, 14, 14, bias=False), modeling_gar.py:54-60) as a
+    callable: binary mask tiles [T, 3, H, W] -> mask embeddings [T, C_v, g, g] (modeling_gar.py:326-328). The mask half of the
+    patch-embed GEMM run on its own (gar_patch_embed with zero weights in the pixel slots, or gar_patch_im2col + gar_gemm); the
+    result is a channel-first VIEW of token-major storage, which is what ``mllm.get_image_features(mask_embeds=)`` reads."""
+
+    def __init__(self, model):
+        self._m = model
+
+    @property
+    def weight(self):       # [C_v, 3, p, p], reconstructed from the fused patch-embed operand (fp32 master in model dtype)
+        m = self._m
+        v = m.config.mllm_config.vision_config
+        pp = v.patch_size * v.patch_size
+        return m.w_patch[:, 3 * pp:6 * pp].reshape(-1, 3, v.patch_size, v.patch_size)
+
+    def __call__(self, binary_mask: torch.Tensor) -> torch.Tensor:
+        return self._m._mask_embed(binary_mask)
 
 
 class GenerationPipeline:
@@ -254,11 +300,20 @@ class GARModel:
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
     DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
-    FUSE_NORM_MAX_BATCH = 16      # largest decode batch that folds RMSNorm into the skinny-GEMM prologue
+    FUSE_NORM_MAX_BATCH = 16      # largest decode batch that keeps `down` un-split (f32 / plain weights: RMSNorm in the GEMV prologue)
+    # The LAST Llama layer of a prefill computes attention / o / gate-up / down for the last prompt row of every sequence only:
+    # the head reads nothing else (modeling_perception_lm.py:545-552, `lm_head(hidden_states[:, slice_indices, :])`) and the
+    # decode steps read the layer's K / V rows, which the qkv GEMM still writes for every row. Exact w.r.t. the reference,
+    # which computes and discards the other S - 1 rows; 2.5 % of a region's GEMM + attention work at GAR-1B / 1024^2.
+    PRUNE_LAST_PREFILL_LAYER = True
 
     def __init__(self, config: GARConfig, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
-                 device: str = "cuda:0", prefill_chunk: Optional[int] = None):
+                 device: str = "cuda:0", prefill_chunk: Optional[int] = None, keep_plain_weights: bool = False):
         self.device = torch.device(device)
+        # bf16 keeps ONE copy of every weight: the norm-folded forms (ViT qkv / fc1, Llama qkv / gate-up) serve the tile GEMMs
+        # (row_scale), the decode GEMVs (norm_folded) and — behind a unit-gain norm pass — the shapes neither takes.
+        # keep_plain_weights=True also keeps the un-folded copies (+1.6 GB GAR-1B, +11 GB GAR-8B): A/B switch for FOLD_NORMS = False
+        self.keep_plain_weights = bool(keep_plain_weights)
         hip.require_device(self.device.index or 0)
         self.config = config
         self.dtype = dtype
@@ -268,6 +323,8 @@ class GARModel:
         with torch.cuda.device(self.device):
             self._prepare_weights(weights)
         self.mllm = _MllmFacade(self)
+        self.mask_patch_embedding = _MaskPatchEmbedding(self)
+        self._mask_only_w = {}
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._graphs: Dict[tuple, object] = {}
         self._llm_lru: List[tuple] = []
@@ -279,8 +336,8 @@ class GARModel:
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
-    def from_synthetic(cls, config: GARConfig, seed: int = 0, dtype=torch.bfloat16, device="cuda:0"):
-        return cls(config, synthetic_weights(config, seed), dtype, device)
+    def from_synthetic(cls, config: GARConfig, seed: int = 0, dtype=torch.bfloat16, device="cuda:0", **kw):
+        return cls(config, synthetic_weights(config, seed), dtype, device, **kw)
 
     @classmethod
     def from_pretrained(cls, path: str, dtype=torch.bfloat16, device="cuda:0", config: GARConfig = None):
@@ -390,6 +447,7 @@ class GARModel:
             return out.reshape(w.shape[0], H * hdp)
 
         fold = self.dtype == torch.bfloat16
+        plain = not fold or self.keep_plain_weights
 
         def fold_ln(w, bias, gamma, beta):
             """LN(x) W^T + b = rstd * (x Wc^T) + b': Wc = W diag(gamma) with every row's mean removed (the mean subtraction
@@ -399,19 +457,24 @@ class GARModel:
 
         for i in range(v.depth):
             b = f"{VT}blocks.{i}."
-            extra = {}
+            blk = {}
             if fold:
                 qw, qb = pad_qkv(W[b + "attn.qkv.weight"]), pad_qkv(W[b + "attn.qkv.bias"])
-                extra["qkv_wf"], extra["qkv_bf"] = fold_ln(qw, qb, W[b + "norm1.weight"], W[b + "norm1.bias"])
-                extra["fc1_wf"], extra["fc1_bf"] = fold_ln(W[b + "mlp.fc1.weight"], W[b + "mlp.fc1.bias"],
-                                                           W[b + "norm2.weight"], W[b + "norm2.bias"])
-            self.vblocks.append(dict(**extra, **dict(
-                n1=(d(W[b + "norm1.weight"]), d(W[b + "norm1.bias"])),
-                qkv_w=d(pad_qkv(W[b + "attn.qkv.weight"])), qkv_b=d(pad_qkv(W[b + "attn.qkv.bias"])),
-                proj_w=d(pad_proj(W[b + "attn.proj.weight"])), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
-                n2=(d(W[b + "norm2.weight"]), d(W[b + "norm2.bias"])),
-                fc1_w=d(W[b + "mlp.fc1.weight"]), fc1_b=d(W[b + "mlp.fc1.bias"]),
-                fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"]))))
+                blk["qkv_wf"], blk["qkv_bf"] = fold_ln(qw, qb, W[b + "norm1.weight"], W[b + "norm1.bias"])
+                blk["fc1_wf"], blk["fc1_bf"] = fold_ln(W[b + "mlp.fc1.weight"], W[b + "mlp.fc1.bias"],
+                                                       W[b + "norm2.weight"], W[b + "norm2.bias"])
+            if plain:
+                blk.update(n1=(d(W[b + "norm1.weight"]), d(W[b + "norm1.bias"])),
+                           qkv_w=d(pad_qkv(W[b + "attn.qkv.weight"])), qkv_b=d(pad_qkv(W[b + "attn.qkv.bias"])),
+                           n2=(d(W[b + "norm2.weight"]), d(W[b + "norm2.bias"])),
+                           fc1_w=d(W[b + "mlp.fc1.weight"]), fc1_b=d(W[b + "mlp.fc1.bias"]))
+            blk.update(proj_w=d(pad_proj(W[b + "attn.proj.weight"])), proj_b=d(W[b + "attn.proj.bias"]), g1=d(W[b + "gamma_1"]),
+                       fc2_w=d(W[b + "mlp.fc2.weight"]), fc2_b=d(W[b + "mlp.fc2.bias"]), g2=d(W[b + "gamma_2"]))
+            self.vblocks.append(blk)
+        # unit LayerNorm / RMSNorm parameters: a folded weight carries its norm's gain (and bias), so where no folded-norm
+        # kernel takes a shape the norm runs as its own pass with gamma = 1, beta = 0 in front of the SAME weight
+        self.unit_ln = (torch.ones(D, dtype=self.dtype, device=self.device), torch.zeros(D, dtype=self.dtype, device=self.device)) \
+            if fold else None
         self.pj = dict(w1=d(W[PJ + "linear_1.weight"]), b1=d(W[PJ + "linear_1.bias"]),
                        w2=d(W[PJ + "linear_2.weight"]), b2=d(W[PJ + "linear_2.bias"]))
         sin, cos = _rope2d_tables(v)
@@ -434,15 +497,17 @@ class GARModel:
             g, u = W[b + "mlp.gate_proj.weight"], W[b + "mlp.up_proj.weight"]
             # [gate16 | up16] row interleave expected by GAR_EPI_SWIGLU
             gu = torch.stack([g.view(F // 16, 16, -1), u.view(F // 16, 16, -1)], dim=1).reshape(2 * F, -1)
-            extra = {}
-            if fold:          # RMSNorm folded: W diag(g) (prefill only; the decode GEMVs keep the plain weights)
+            ly = {}
+            if fold:          # RMSNorm folded: W diag(g) — the tile GEMM's row_scale form, the decode GEMVs' norm_folded form
                 # rows in the order the fused RoPE epilogue wants (identity for head_dim 64): self.qkv_f_permuted
-                extra["qkv_f"] = d((qkv.float() * W[b + "input_layernorm.weight"].float()[None, :])[qkv_order])
-                extra["gu_f"] = d(gu.float() * W[b + "post_attention_layernorm.weight"].float()[None, :])
-            self.layers.append(dict(**extra, ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv),
-                                    o=d(W[b + "self_attn.o_proj.weight"]),
-                                    ln2=d(W[b + "post_attention_layernorm.weight"]), gu=d(gu),
-                                    down=d(W[b + "mlp.down_proj.weight"])))
+                ly["qkv_f"] = d((qkv.float() * W[b + "input_layernorm.weight"].float()[None, :])[qkv_order])
+                ly["gu_f"] = d(gu.float() * W[b + "post_attention_layernorm.weight"].float()[None, :])
+            if plain:
+                ly.update(ln1=d(W[b + "input_layernorm.weight"]), qkv=d(qkv), ln2=d(W[b + "post_attention_layernorm.weight"]),
+                          gu=d(gu))
+            ly.update(o=d(W[b + "self_attn.o_proj.weight"]), down=d(W[b + "mlp.down_proj.weight"]))
+            self.layers.append(ly)
+        self.unit_rms = torch.ones(t.hidden_size, dtype=self.dtype, device=self.device) if fold else None
         self.final_norm = d(W[LM + "norm.weight"])
         self.inv_freq = _llama_inv_freq(t)
         self.crop_ids_dev = torch.tensor(self.crop_tokens_ids, dtype=torch.int64, device=self.device)
@@ -493,10 +558,12 @@ class GARModel:
     # ---- vision tower + projector (A1-A6) -----------------------------------------------------------------------------
     @_on_model_device
     def get_image_features(self, pixel_values: torch.Tensor, global_mask_values: Optional[torch.Tensor] = None,
-                           pooled: bool = True, out: Optional[torch.Tensor] = None):
+                           pooled: bool = True, out: Optional[torch.Tensor] = None,
+                           mask_embeds: Optional[torch.Tensor] = None):
         """[Tt,3,H,W] (+ mask values of the same shape, still in the processor's [-1,1] encoding) -> [Tt, P*P, C_l].
         ``pooled=False`` stops after the projector and returns its [Tt * tokens, C_l] output (cls rows included),
-        written into ``out`` when given."""
+        written into ``out`` when given. ``mask_embeds`` [Tt, C_v, g, g] (instead of ``global_mask_values``): the reference's
+        form — the mask-embedding conv's output, added to the patch embeddings (modeling_perception_lm.py:195-196)."""
         cfg = self.config
         v = cfg.mllm_config.vision_config
         C_l = cfg.mllm_config.text_config.hidden_size
@@ -540,6 +607,12 @@ class GARModel:
             A = self._buf(key, "im2col", (Tt * n, self.Kp))
             ops.patch_im2col(pix, msk, A, v.patch_size, cfg.prompt_numbers)
             ops.gemm(A, self.w_patch, x2, hip.EPI_PATCH_POS, pos=self.pos, tokens_in=n, tokens_out=N, token_offset=self.npt)
+        if mask_embeds is not None:         # x = x + mask_embeds.flatten(2).transpose(1, 2) on the patch rows
+            assert msk is None, "mask_embeds and global_mask_values are alternatives"
+            me = mask_embeds.to(self.device, self.dtype)
+            if tuple(me.shape) != (Tt, D, v.grid, v.grid):
+                raise ValueError(f"mask_embeds {tuple(me.shape)} should be {(Tt, D, v.grid, v.grid)}")
+            ops.tokens_add(x, me.flatten(2).transpose(1, 2).contiguous(), self.npt)
         if self.npt:
             ops.cls_pos_fill(x, self.cls, self.pos)
         ops.layernorm(x2, *self.norm_pre, v.ln_eps)
@@ -548,18 +621,26 @@ class GARModel:
         # Folded LayerNorms (bf16, passes large enough for the tile GEMM): qkv and fc1 read the residual stream x itself with
         # the folded weights and scale their accumulator rows by rstd; proj and fc2 write x's row statistics from their
         # epilogues; a one-thread-per-row kernel turns them into rstd. No LayerNorm pass, no normalised copy of x.
-        fold = (self.FOLD_NORMS and fused and Vr is not None and "qkv_wf" in self.vblocks[0] and
-                ops.tile_gemm_takes(Tt * N, D) and D % 64 == 0)
+        M = Tt * N
+        has_folded = "qkv_wf" in self.vblocks[0]
+        use_folded_w = has_folded and (self.FOLD_NORMS or "qkv_w" not in self.vblocks[0])      # bf16 keeps only these by default
+        fold = (self.FOLD_NORMS and fused and Vr is not None and has_folded and D % 64 == 0 and
+                ops.tile_gemm_takes(M, 3 * Da, D, epilogue=hip.EPI_QKV_ROPE, row_scale=True) and
+                ops.tile_gemm_takes(M, D, Da, epilogue=hip.EPI_BIAS_SCALE_RES, row_stats=True) and
+                ops.tile_gemm_takes(M, Dm, D, epilogue=hip.EPI_BIAS_GELU, row_scale=True) and
+                ops.tile_gemm_takes(M, D, Dm, epilogue=hip.EPI_BIAS_SCALE_RES, row_stats=True))
+        # the cls key (row 0) enters through the softmax's initial state: 1 + 1024 keys are 16 kv tiles, not 17 (built for ONE
+        # prefix row: a tower with cls + register tokens keeps them as ordinary keys)
+        kv_prefix = 1 if (self.VIT_CLS_KEY_FOLD and self.npt == 1 and N > 1) else 0
         if fold:
-            rstd = self._buf(key, "rstd", (Tt * N,), torch.float32)
-            stats = self._buf(key, "stats", (Tt * N, D // 64, 2), torch.float32)
+            rstd = self._buf(key, "rstd", (M,), torch.float32)
+            stats = self._buf(key, "stats", (M, D // 64, 2), torch.float32)
             ops.row_rstd(x2, v.ln_eps, False, rstd)                  # LN1 of block 0: its input came out of norm_pre
             for bi, blk in enumerate(self.vblocks):
                 if not ops.gemm_qkv_rope(x2, blk["qkv_wf"], blk["qkv_bf"], att, Q, K, self.vit_sin, self.vit_cos, H, hd, N,
                                          Npad, self.npt, q_scale, V=Vr, row_scale=rstd):
-                    raise hip.GarError("folded qkv GEMM refused a shape tile_gemm_takes() accepted")
-                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True,
-                              kv_prefix=self.npt if self.VIT_CLS_KEY_FOLD and N > 1 else 0)
+                    raise hip.GarError("folded qkv GEMM refused a shape gar_gemm_tile_takes() accepted")
+                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True, kv_prefix=kv_prefix)
                 ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"],
                          row_stats=stats)
                 ops.row_stats_finalize(stats, D, v.ln_eps, False, rstd)
@@ -569,36 +650,46 @@ class GARModel:
                          row_stats=None if last else stats)
                 if not last:
                     ops.row_stats_finalize(stats, D, v.ln_eps, False, rstd)
-        hbuf = None if fold else self._buf(key, "h", (Tt * N, D))
+        hbuf = None if fold else self._buf(key, "h", (M, D))
+
+        def ln_operand(blk, which):
+            """stand-alone LayerNorm of the residual stream into hbuf + the (weight, bias) that goes with it: the plain pair
+            behind the block's own gamma / beta, or — bf16 keeps only those — the FOLDED pair behind a unit LayerNorm
+            ((x - mean) rstd: gamma, beta and the row centring live in the weight, LN(x) W^T + b = ((x - mean) rstd) Wc^T + b')."""
+            if use_folded_w:
+                ops.layernorm(x2, self.unit_ln[0], self.unit_ln[1], v.ln_eps, out=hbuf)
+                return (blk["qkv_wf"], blk["qkv_bf"]) if which == 1 else (blk["fc1_wf"], blk["fc1_bf"])
+            n = blk["n1" if which == 1 else "n2"]
+            ops.layernorm(x2, n[0], n[1], v.ln_eps, out=hbuf)
+            return (blk["qkv_w"], blk["qkv_b"]) if which == 1 else (blk["fc1_w"], blk["fc1_b"])
+
         for blk in ([] if fold else self.vblocks):
-            ops.layernorm(x2, *blk["n1"], v.ln_eps, out=hbuf)
+            qw, qb = ln_operand(blk, 1)
             if fused:
                 if Vr is None and vrow is None:
-                    qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
-                    vrow = qkv.view(-1)[:Tt * N * Da].view(Tt * N, Da)
+                    qkv = self._buf(key, "qkv", (M, 3 * Da))
+                    vrow = qkv.view(-1)[:M * Da].view(M, Da)
                     Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
                 # with V= the row-major v output is not written (att stands in for the pointer the ABI wants)
-                fused = ops.gemm_qkv_rope(hbuf, blk["qkv_w"], blk["qkv_b"], att if Vr is not None else vrow, Q, K,
+                fused = ops.gemm_qkv_rope(hbuf, qw, qb, att if Vr is not None else vrow, Q, K,
                                           self.vit_sin, self.vit_cos, H, hd, N, Npad, self.npt, q_scale, V=Vr)
             if fused and Vr is None:
                 ops.vit_v_transpose(vrow, Vt, Tt, N, H, hd, Npad)
             elif not fused:
                 Vr = None
                 if qkv is None:
-                    qkv = self._buf(key, "qkv", (Tt * N, 3 * Da))
+                    qkv = self._buf(key, "qkv", (M, 3 * Da))
                 if Vt is None:
                     Vt = self._buf(key, "Vt", (Tt, H, hd, Npad))
-                ops.gemm(hbuf, blk["qkv_w"], qkv, hip.EPI_BIAS, bias=blk["qkv_b"])
+                ops.gemm(hbuf, qw, qkv, hip.EPI_BIAS, bias=qb)
                 ops.vit_qkv_post(qkv, self.vit_sin, self.vit_cos, Q, K, Vt, Tt, N, self.npt, H, hd, Npad, q_scale)
             if Vr is not None:      # v left the qkv GEMM head-major like k: the attention transposes it on its LDS reads
-                # the cls key (row 0) enters through the softmax's initial state: 1 + 1024 keys are 16 kv tiles, not 17
-                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True,
-                              kv_prefix=self.npt if self.VIT_CLS_KEY_FOLD and N > 1 else 0)
+                ops.attention(Q, K, Vr, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False, v_row_major=True, kv_prefix=kv_prefix)
             else:
                 ops.attention(Q, K, Vt, att, Tt, H, H, hd, N, Npad, N, Npad, causal=False)
             ops.gemm(att, blk["proj_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["proj_b"], residual=x2, gamma=blk["g1"])
-            ops.layernorm(x2, *blk["n2"], v.ln_eps, out=hbuf)
-            ops.gemm(hbuf, blk["fc1_w"], f1v, hip.EPI_BIAS_GELU, bias=blk["fc1_b"])
+            fw, fb = ln_operand(blk, 2)
+            ops.gemm(hbuf, fw, f1v, hip.EPI_BIAS_GELU, bias=fb)
             ops.gemm(f1v, blk["fc2_w"], x2, hip.EPI_BIAS_SCALE_RES, bias=blk["fc2_b"], residual=x2, gamma=blk["g2"])
         # projector over all N tokens of a tile (cls row included, dropped by the pooling window)
         p1 = f1.view(-1)[:Tt * N * C_l].view(Tt * N, C_l)
@@ -614,6 +705,36 @@ class GARModel:
         feats = self._buf(key, "feats", (Tt, P * P, C_l))
         ops.pool2x2(p2, feats, v.grid, in_tile_tokens=N, in_token_offset=self.npt)
         return feats
+
+    @_on_model_device
+    def _mask_embed(self, binary_mask: torch.Tensor) -> torch.Tensor:
+        """mask_patch_embedding(binary) (modeling_gar.py:326-328): [T,3,H,W] in {0,1} -> [T, C_v, g, g] (view of [T, g*g, C_v])."""
+        v = self.config.mllm_config.vision_config
+        D, n, g = v.embed_dim, v.num_patches, v.grid
+        mb = binary_mask.to(self.device, self.dtype)
+        if mb.dim() == 5:
+            mb = mb.flatten(0, 1)
+        mb = mb.contiguous()
+        T = mb.shape[0]
+        out = torch.empty(T, n, D, dtype=self.dtype, device=self.device)
+        done = False
+        if self.w_patch_gather is not None:
+            if "gather" not in self._mask_only_w:       # the gather-ordered operand with the pixel tensor's slots zeroed + a zero pos table
+                wg = self.w_patch_gather.clone().view(D, 2, -1)
+                wg[:, 0] = 0
+                self._mask_only_w["gather"] = (wg.view(D, -1), torch.zeros(n, D, dtype=self.dtype, device=self.device))
+            wg, zpos = self._mask_only_w["gather"]
+            done = ops.patch_embed(mb, mb, wg, zpos, out, v.patch_size, 0)       # pixel slots carry zero weights: any finite tensor does
+        if not done:
+            pp = v.patch_size * v.patch_size
+            if "im2col" not in self._mask_only_w:       # the mask conv's weight in the pixel columns of the im2col operand
+                w = torch.zeros_like(self.w_patch)
+                w[:, :3 * pp] = self.w_patch[:, 3 * pp:6 * pp]
+                self._mask_only_w["im2col"] = w
+            A = torch.empty(T * n, self.Kp, dtype=self.dtype, device=self.device)
+            ops.patch_im2col(mb, None, A, v.patch_size, self.config.prompt_numbers)
+            ops.gemm(A, self._mask_only_w["im2col"], out.view(T * n, D))
+        return out.view(T, g, g, D).permute(0, 3, 1, 2)
 
     # ---- inputs_embeds: embedding + placeholder scatter + RoI replay (A7-A11) -----------------------------------------
     @_on_model_device
@@ -742,63 +863,117 @@ class GARModel:
         return key, st
 
     def _prefill(self, embeds: torch.Tensor, st, Smax: int, b0: int = 0):
-        """Prefill of one chunk of sequences [B,S,C] whose KV goes to rows b0..b0+B of the shared cache."""
+        """Prefill of one chunk of sequences [B,S,C] whose KV goes to rows b0..b0+B of the shared cache. Returns the last
+        prompt row of every sequence after the last layer ([B, C] row-strided view): what the head reads."""
         t = self.config.mllm_config.text_config
         B, S, C_l = embeds.shape
         Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
         key = ("prefill", B, S)
         h = embeds.view(B * S, C_l)
-        xn = None                                      # the normalised copy of h: only without folded norms
+        M = B * S
+        qd = (Hq + 2 * Hkv) * hd
         Spad = _round_up(S, 64)
         Q = self._buf(key, "Q", (B, Hq, Spad, hd))
-        att = self._buf(key, "att", (B * S, Hq * hd))
-        ff = self._buf(key, "ff", (B * S, F))
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         lp = st["left_pad"][b0:b0 + B]
+        bf16 = self.dtype == torch.bfloat16
+        has_folded = "qkv_f" in self.layers[0]
+        use_folded_w = has_folded and (self.FOLD_NORMS or "qkv" not in self.layers[0])         # bf16 keeps only these by default
         # Folded RMSNorms (bf16, tile-GEMM sized passes): qkv and gate/up read the residual stream h with W diag(g) and scale
         # their accumulator rows by rstd; o and down write h's row sums of squares from their epilogues (see get_image_features)
-        fold = (self.FOLD_NORMS and self.dtype == torch.bfloat16 and "qkv_f" in self.layers[0] and
-                ops.tile_gemm_takes(B * S, C_l) and C_l % 64 == 0)
+        fold = (self.FOLD_NORMS and bf16 and has_folded and C_l % 64 == 0 and
+                ops.tile_gemm_takes(M, qd, C_l, row_scale=True) and
+                ops.tile_gemm_takes(M, C_l, Hq * hd, epilogue=hip.EPI_RES, row_stats=True) and
+                ops.tile_gemm_takes(M, 2 * F, C_l, epilogue=hip.EPI_SWIGLU, row_scale=True) and
+                ops.tile_gemm_takes(M, C_l, F, epilogue=hip.EPI_RES, row_stats=True))
+        rstd = stats = xn = None
         if fold:
-            rstd = self._buf(key, "rstd", (B * S,), torch.float32)
-            stats = self._buf(key, "stats", (B * S, C_l // 64, 2), torch.float32)
+            rstd = self._buf(key, "rstd", (M,), torch.float32)
+            stats = self._buf(key, "stats", (M, C_l // 64, 2), torch.float32)
             ops.row_rstd(h, t.rms_norm_eps, True, rstd)                  # input_layernorm of layer 0: h came from the embedding pass
         else:
-            xn = self._buf(key, "xn", (B * S, C_l))
+            xn = self._buf(key, "xn", (M, C_l))                          # the normalised copy of h: only without folded norms
         fused_qkv = fold and self.LLM_QKV_EPILOGUE and hd in (64, 128)
-        if not fused_qkv and fold and self.qkv_f_permuted:
-            raise hip.GarError("qkv_f is stored in the fused epilogue's row order: LLM_QKV_EPILOGUE has to be set before the "
-                               "model is built")
+        strip = use_folded_w and self.qkv_f_permuted        # q / k head columns of a qkv_f product are in the fused epilogue's order
+        L = len(self.layers)
+        prune = self.PRUNE_LAST_PREFILL_LAYER and S > 1
+        att = ff = None
+        if L > 1 or not prune:
+            att = self._buf(key, "att", (M, Hq * hd))
+            ff = self._buf(key, "ff", (M, F))
         for li, ly in enumerate(self.layers):
+            last = li + 1 == L
             Kc, Vc = st["Kc"][li][b0:b0 + B], st["Vc"][li][b0:b0 + B]         # this chunk's rows of the shared cache
+            # ---- q / k / v of EVERY row (the decode steps read this layer's K / V rows too)
             if fused_qkv:
                 if not ops.gemm_qkv_rope_llm(h, ly["qkv_f"], Q, Kc, Vc, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, 0, None,
                                              q_scale, left_pad=lp, row_scale=rstd):
-                    raise hip.GarError("fused qkv GEMM refused a shape tile_gemm_takes() accepted")
+                    raise hip.GarError("fused qkv GEMM refused a shape gar_gemm_tile_takes() accepted")
             else:
+                qb = self._qkv_buf(key, B, S, Hq, Hkv, hd)
                 if fold:
-                    ops.gemm(h, ly["qkv_f"], self._qkv_buf(key, B, S, Hq, Hkv, hd), row_scale=rstd)
+                    ops.gemm(h, ly["qkv_f"], qb, row_scale=rstd)
+                elif use_folded_w:      # unit-gain RMSNorm pass + the folded weight (its gain is in W)
+                    ops.rmsnorm(h, self.unit_rms, t.rms_norm_eps, out=xn)
+                    ops.gemm(xn, ly["qkv_f"], qb)
                 else:
                     ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
-                    ops.gemm(xn, ly["qkv"], self._qkv_buf(key, B, S, Hq, Hkv, hd))
-                ops.llm_qkv_post(self._qkv_buf(key, B, S, Hq, Hkv, hd), cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, 0,
-                                 None, q_scale, left_pad=lp)
+                    ops.gemm(xn, ly["qkv"], qb)
+                ops.llm_qkv_post(qb, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, q_scale, left_pad=lp,
+                                 strip_order=strip)
+            if last and prune:
+                return self._prefill_tail(ly, h, Q, Kc, Vc, st, key, B, S, Spad, Smax, lp)
             ops.attention(Q, Kc, Vc, att, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp, v_row_major=True)
             if fold:
                 ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h, row_stats=stats)
                 ops.row_stats_finalize(stats, C_l, t.rms_norm_eps, True, rstd)
                 ops.gemm(h, ly["gu_f"], ff, hip.EPI_SWIGLU, row_scale=rstd)
-                last = li + 1 == len(self.layers)
                 ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h, row_stats=None if last else stats)
                 if not last:
                     ops.row_stats_finalize(stats, C_l, t.rms_norm_eps, True, rstd)
             else:
                 ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
-                ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
-                ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+                if use_folded_w:
+                    ops.rmsnorm(h, self.unit_rms, t.rms_norm_eps, out=xn)
+                    ops.gemm(xn, ly["gu_f"], ff, hip.EPI_SWIGLU)
+                else:
+                    ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
+                    ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
                 ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         return h.view(B, S, C_l)[:, S - 1, :]                                   # row-strided view [B, C]
+
+    def _prefill_tail(self, ly, h, Q, Kc, Vc, st, key, B, S, Spad, Smax, lp):
+        """The last layer of a prefill behind its qkv GEMM, for the LAST prompt row of each of the B sequences only
+        (PRUNE_LAST_PREFILL_LAYER): single-row attention over the sequence's S cache rows with the split-KV decode kernel —
+        the query is read in place from row S - 1 of Q [B, Hq, Spad, hd] — then o / RMSNorm / gate-up / down as B-row GEMMs on
+        the rows h[b, S - 1] (row-strided views, updated in place like the full-width layers update h)."""
+        t = self.config.mllm_config.text_config
+        C_l = h.shape[1]
+        Hq, Hkv, hd, F = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size
+        hl = h.view(B, S, C_l)[:, S - 1, :]
+        attl = self._buf(key, "att_last", (B, Hq * hd))
+        ffl = self._buf(key, "ff_last", (B, F))
+        kv_len = st["counters"][3:4]                    # scratch word of the counters: the prompt length, for the kernel's kv_len_dev
+        kv_len.fill_(S)
+        nsplit = max(1, min(64, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
+        dws = self._buf(key, "attn_ws_last", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
+        ops.attention_decode(Q[:, :, S - 1], Kc, Vc, attl, B, Hq, Hkv, hd, Smax, kv_len, nsplit, dws, kv_start=lp,
+                             q_stride=Spad * hd)
+        ops.gemm(attl, ly["o"], hl, hip.EPI_RES, residual=hl)
+        if "gu_f" in ly and (self.FOLD_NORMS or "gu" not in ly):
+            if B <= 64:     # RMSNorm inside the GEMM: gain in the weight, row sums of squares off the matrix pipe
+                ops.gemm(hl, ly["gu_f"], ffl, hip.EPI_SWIGLU, norm_folded=True, norm_eps=t.rms_norm_eps)
+            else:
+                xnl = self._buf(key, "xn_last", (B, C_l))
+                ops.rmsnorm(hl, self.unit_rms, t.rms_norm_eps, out=xnl)
+                ops.gemm(xnl, ly["gu_f"], ffl, hip.EPI_SWIGLU)
+        else:
+            xnl = self._buf(key, "xn_last", (B, C_l))
+            ops.rmsnorm(hl, ly["ln2"], t.rms_norm_eps, out=xnl)
+            ops.gemm(xnl, ly["gu"], ffl, hip.EPI_SWIGLU)
+        ops.gemm(ffl, ly["down"], hl, hip.EPI_RES, residual=hl)
+        return hl
 
     def _qkv_buf(self, key, B, S, Hq, Hkv, hd):
         """the [B*S, (Hq + 2 Hkv) hd] qkv GEMM output of the unfused prefill path (f32 / FOLD_NORMS off): lazily allocated"""
@@ -843,45 +1018,68 @@ class GARModel:
         nsplit = max(1, min(64, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
-        fuse = B <= self.FUSE_NORM_MAX_BATCH     # every block redoes x*g in the prologue: only pays for <= 16 rows
+        bf16 = self.dtype == torch.bfloat16
+        use_folded_w = "qkv_f" in self.layers[0] and (self.FOLD_NORMS or "qkv" not in self.layers[0])
+        # how the two RMSNorms of a layer reach their GEMVs:
+        #   folded  (bf16, B <= 64): gain in the weight (qkv_f / gu_f), row sums of squares off the matrix pipe inside the GEMV
+        #           (gar_gemm_params.norm_folded) — no norm launch, no normalised copy, ONE copy of the weights
+        #   fuse    (plain weights, B <= 16): x * g in the GEMV prologue (gar_gemm_params.norm_w)
+        #   else    a norm launch in front of the GEMV (unit gain when only the folded weights exist)
+        folded = use_folded_w and bf16 and B <= 64
+        fuse = not use_folded_w and B <= self.FUSE_NORM_MAX_BATCH
+        strip = use_folded_w and self.qkv_f_permuted
         # `down` (K = intermediate size, only hidden/16 weight tiles) streams from DOWN_SPLIT_K x the workgroups as K slices
-        # whose fp32 products are reduced — with the residual add and the next RMSNorm — by the launch that follows anyway
-        # (gar_gemm's split_k and gar_splitk_residual_rmsnorm take at most SPLITK_MAX_ROWS rows; larger batches keep the tile
-        # GEMM with EPI_RES + a separate RMSNorm)
-        split = self.DOWN_SPLIT_K if (not fuse and B <= self.SPLITK_MAX_ROWS and self.dtype == torch.bfloat16
+        # whose fp32 products are reduced — with the residual add and, on the last layer, the final RMSNorm — by the launch that
+        # follows anyway (gar_gemm's split_k and gar_splitk_residual_rmsnorm take at most SPLITK_MAX_ROWS rows; larger batches
+        # keep EPI_RES)
+        split = self.DOWN_SPLIT_K if (B > self.FUSE_NORM_MAX_BATCH and B <= self.SPLITK_MAX_ROWS and bf16
                                       and F % (64 * self.DOWN_SPLIT_K) == 0 and C_l <= 4096) else 1
         partial = self._buf(key, "down_partial", (split, B, C_l), torch.float32) if split > 1 else None
         normed = None
-        gu_folded = (self.DECODE_GU_NORM_FOLDED and not fuse and self.dtype == torch.bfloat16 and B <= 64 and
-                     "gu_f" in self.layers[0])
+        gu_folded = folded and (self.DECODE_GU_NORM_FOLDED or "gu" not in self.layers[0])
+        qkv_folded = folded and (self.DECODE_GU_NORM_FOLDED or "qkv" not in self.layers[0])
+        L = len(self.layers)
+        xn_ready = False            # xn holds RMSNorm(h; this layer's input_layernorm) — written by the previous layer's reduce
         for li, ly in enumerate(self.layers):
-            if fuse:
+            if qkv_folded:
+                ops.gemm(h, ly["qkv_f"], qkv, norm_folded=True, norm_eps=t.rms_norm_eps)
+            elif fuse:
                 ops.gemm(h, ly["qkv"], qkv, norm_w=ly["ln1"], norm_eps=t.rms_norm_eps)
             else:
-                if split == 1 or li == 0:
-                    ops.rmsnorm(h, ly["ln1"], t.rms_norm_eps, out=xn)
-                ops.gemm(xn, ly["qkv"], qkv)
+                if not xn_ready:
+                    ops.rmsnorm(h, self.unit_rms if use_folded_w else ly["ln1"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["qkv_f"] if use_folded_w else ly["qkv"], qkv)
             # bf16: RoPE, q scale and the cache append run inside the attention launch (one launch instead of two)
             if not (self.DECODE_ATTN_TAKES_QKV and
                     ops.attention_decode_qkv(qkv, cos, sin, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, pos_dev,
-                                             q_scale, nsplit, dws, left_pad=st["left_pad"])):
+                                             q_scale, nsplit, dws, left_pad=st["left_pad"], strip_order=strip)):
                 ops.llm_qkv_post(qkv, cos, sin, Q, st["Kc"][li], st["Vc"][li], B, 1, 1, Hq, Hkv, hd, Smax, 0, pos_dev, q_scale,
-                                 left_pad=st["left_pad"])
+                                 left_pad=st["left_pad"], strip_order=strip)
                 ops.attention_decode(Q, st["Kc"][li], st["Vc"][li], att, B, Hq, Hkv, hd, Smax, kvlen_dev, nsplit, dws,
                                      kv_start=st["left_pad"])
             ops.gemm(att, ly["o"], h, hip.EPI_RES, residual=h)
-            if fuse:
-                ops.gemm(h, ly["gu"], ff, hip.EPI_SWIGLU, norm_w=ly["ln2"], norm_eps=t.rms_norm_eps)
-            elif gu_folded:     # W diag(g) + row sums of squares off the matrix pipe: no RMSNorm launch, no normalised copy
+            if gu_folded:       # W diag(g) + row sums of squares off the matrix pipe: no RMSNorm launch, no normalised copy
                 ops.gemm(h, ly["gu_f"], ff, hip.EPI_SWIGLU, norm_folded=True, norm_eps=t.rms_norm_eps)
+            elif fuse:
+                ops.gemm(h, ly["gu"], ff, hip.EPI_SWIGLU, norm_w=ly["ln2"], norm_eps=t.rms_norm_eps)
             else:
-                ops.rmsnorm(h, ly["ln2"], t.rms_norm_eps, out=xn)
-                ops.gemm(xn, ly["gu"], ff, hip.EPI_SWIGLU)
+                ops.rmsnorm(h, self.unit_rms if use_folded_w else ly["ln2"], t.rms_norm_eps, out=xn)
+                ops.gemm(xn, ly["gu_f"] if use_folded_w else ly["gu"], ff, hip.EPI_SWIGLU)
+            xn_ready = False
             if split > 1:
                 ops.gemm(ff, ly["down"], None, partial=partial)
-                nxt = self.layers[li + 1]["ln1"] if li + 1 < len(self.layers) else self.final_norm
-                ops.splitk_residual_rmsnorm(partial, h, nxt, t.rms_norm_eps, out=xn)    # h += down; xn = norm(h)
-                normed = xn
+                lastl = li + 1 == L
+                # h += down (one rounding, like EPI_RES); the reduce also writes the RMSNorm the next GEMV wants when that GEMV
+                # does not take it folded: the final norm for the head, or the next layer's input_layernorm
+                if lastl:
+                    ops.splitk_residual_rmsnorm(partial, h, self.final_norm, t.rms_norm_eps, out=xn)
+                    normed = xn
+                elif qkv_folded:
+                    ops.splitk_residual_rmsnorm(partial, h, None, t.rms_norm_eps, out=None)
+                else:
+                    nxt = self.unit_rms if use_folded_w else self.layers[li + 1]["ln1"]
+                    ops.splitk_residual_rmsnorm(partial, h, nxt, t.rms_norm_eps, out=xn)
+                    xn_ready = True
             else:
                 ops.gemm(ff, ly["down"], h, hip.EPI_RES, residual=h)
         logits = self._head(h, B, out_tokens, st, normed=normed)
@@ -952,6 +1150,7 @@ class GARModel:
             get = (lambda k, d=None: gc.get(k, d)) if isinstance(gc, dict) else (lambda k, d=None: getattr(gc, k, d))
             if get("do_sample", False):
                 raise hip.GarError("only greedy decoding (do_sample=False) is implemented, as the reference's callers use")
+            _refuse_non_greedy(get)
             max_new_tokens = max_new_tokens or get("max_new_tokens")
             if eos_token_id is None:
                 eos_token_id = get("eos_token_id")
@@ -965,7 +1164,7 @@ class GARModel:
         # (HF's convention for generation: prompts of different lengths right-aligned, zeros in front) is supported: a
         # sequence keeps its rows in the padded layout, its RoPE positions count from its first real token and the padding
         # keys stay hidden (HF: position_ids = cumsum(mask) - 1, causal mask AND attention_mask).
-        left_pad = None
+        left_pad = am_dev = None
         if attention_mask is not None:
             am = (attention_mask != 0)
             if tuple(am.shape) != (B, S):
@@ -977,8 +1176,9 @@ class GARModel:
                         raise hip.GarError("attention_mask must be LEFT-padded (zeros only in front of every prompt): a "
                                            "right-padded row would be continued after its padding")
                     left_pad = (S - amc.sum(1)).to(torch.int32).to(self.device)
-            else:                      # no host sync: the mask is trusted to be left-padded, its zero count is the pad
-                left_pad = (S - am.to(self.device).sum(1)).to(torch.int32)
+            else:                      # no host sync: the zero count is the pad; the device-side input check (gar_input_check)
+                am_dev = am.to(self.device).contiguous()       # raises INPUT_MASK_NOT_LEFT_PADDED for a row that is not 0...01...1
+                left_pad = (S - am_dev.sum(1)).to(torch.int32)
         # KV capacity in buckets of 256 positions: evaluation loops with a different prompt length per item reuse one
         # cache, one token buffer ([B, Smax], sliced) and one captured decode graph per bucket
         if forced_tokens is not None:
@@ -1007,6 +1207,9 @@ class GARModel:
         # the decode loop below then serves all B sequences of the shared KV cache in one weight pass per token.
         first_logits = []
         self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if am_dev is not None:      # validate=False: the mask's left-padded form is checked on the device, flag read by the caller
+            ops.input_check(input_ids.to(self.device, torch.int64).contiguous(), V, None, 0, None, 0, None, self._input_flags,
+                            attn_mask=am_dev)
         tile_chunks, seq_chunks = self._plan_passes(B, tiles, S)
         proj_all, rows_per_sample = None, 0
         if pixel_values is not None:
@@ -1080,6 +1283,8 @@ class GARModel:
             graph, graph_logits = self._decode_graph(st, B, Smax, out_tokens, skey)
         n_done = 1
         finished_at = [None] * B
+        if ops.KERNEL_TIMERS is not None:       # bench.py's per-kernel timers: the decode steps' launches are priced separately
+            ops.KERNEL_PHASE = "decode:"
         while n_done < max_new_tokens:
             if graph is not None:
                 graph.replay()
@@ -1097,6 +1302,7 @@ class GARModel:
                     self._raise_on_input_flags()        # the poll above synchronised already
                 if fin:
                     break
+        ops.KERNEL_PHASE = ""
         seq = out_tokens[:, :n_done].clone()
         if eos:
             self._all_finished(out_tokens, n_done, eos, finished_at)

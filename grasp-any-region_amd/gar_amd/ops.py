@@ -12,10 +12,12 @@ from .hip import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE, EPI_PAT
                   GemmParams, check, dtype_code, lib, ptr, stream)
 
 
-KERNEL_TIMERS = None     # bench.py sets this to a list to time GEMM launches with HIP events
+KERNEL_TIMERS = None     # bench.py sets this to a list to time launches with HIP events: (kind, flops, bytes, e0, e1)
+KERNEL_PHASE = ""        # "decode:" while GARModel.generate_finish's loop enqueues (prefix of `kind`: the same skinny GEMM
+                         # kernels serve the prompt phase's B-row tail and the decode steps, priced separately by bench.py)
 
 
-def _timed(kind: str, nbytes: float, call):
+def _timed(kind: str, nbytes: float, call, flops: float = 0.0):
     """Run one launch; when bench.py collects timers, bracket it with HIP events on the launch stream."""
     prof = KERNEL_TIMERS
     if prof is not None and not torch.cuda.is_current_stream_capturing():
@@ -23,7 +25,7 @@ def _timed(kind: str, nbytes: float, call):
         e0.record()
         call()
         e1.record()
-        prof.append((kind, 0.0, float(nbytes), e0, e1))
+        prof.append((KERNEL_PHASE + kind, float(flops), float(nbytes), e0, e1))
     else:
         call()
 
@@ -83,17 +85,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         e0.record()
         check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
         e1.record()
-        kind = ("gemm_skinny" if M <= 16 else "gemm_tile") + ("_bf16" if a.dtype == torch.bfloat16 else "_f32")
-        prof.append((kind, 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), e0, e1))
+        # M <= 64: the weight-streaming skinny kernels (decode GEMVs, lm_head, the pruned prefill tail) — HBM-bound, priced on
+        # bytes; everything larger is the MFMA-bound tile GEMM family
+        kind = ("gemm_skinny" if M <= 64 else "gemm_tile") + ("_bf16" if a.dtype == torch.bfloat16 else "_f32")
+        prof.append((KERNEL_PHASE + kind, 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), e0, e1))
         return out
     check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
     return out
 
 
-def tile_gemm_takes(M: int, N: int) -> bool:
-    """True when a bf16 [M, K] x [N, K]^T problem runs on the persistent 256 x 256 tile GEMM (csrc/gemm_pp.hip,
-    gar_gemm_pp_try) — the kernel whose epilogues carry the folded norms (row_scale / row_stats)."""
-    return N >= 256 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
+def tile_gemm_takes(M: int, N: int, K: int = 64, lda: int = 0, ldc: int = 0, ldr: int = 0, epilogue: int = EPI_NONE,
+                    row_scale: bool = False, row_stats: bool = False) -> bool:
+    """True when a bf16 [M, K] x [N, K]^T problem runs on the persistent 256 x 256 tile GEMM (csrc/gemm_pp.hip) — the kernel
+    whose epilogues carry the folded norms (row_scale / row_stats). The LIBRARY's predicate (gar_gemm_tile_takes): tile count,
+    N >= 256, N % 8, row pitches % 8, operands < 4 GiB, epilogue / row_scale pairing. Pointer alignment is the one condition a
+    shape-only question cannot carry: torch allocations are 256-byte aligned and the host only slices them at row boundaries
+    of pitches that are multiples of 8 elements."""
+    p = GemmParams()
+    al = 256                                           # a stand-in, 16-byte aligned address for every operand the epilogue names
+    p.A, p.lda, p.W, p.ldw, p.C, p.ldc = al, lda or K, al, K, al, ldc or (N // 2 if epilogue == EPI_SWIGLU else N)
+    p.M, p.N, p.K, p.epilogue = M, N, K, epilogue
+    if epilogue in (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, hip.EPI_QKV_ROPE):
+        p.bias = al
+    if epilogue in (EPI_RES, EPI_BIAS_SCALE_RES):
+        p.residual, p.ldr = al, ldr or N
+    if epilogue == EPI_BIAS_SCALE_RES:
+        p.gamma = al
+    if epilogue == hip.EPI_QKV_ROPE:                   # the compact-table form with head-major v (what the folded path runs)
+        p.qkv_q = p.qkv_k = p.qkv_v = p.qkv_sin = al
+    if row_scale:
+        p.row_scale = al
+    if row_stats:
+        p.row_stats = al
+    return bool(lib().gar_gemm_tile_takes(hip.GAR_BF16, C.byref(p)))
 
 
 def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[torch.Tensor], eps: float,
@@ -102,8 +126,9 @@ def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[
     when given (the next layer's input_layernorm / the final norm)."""
     S, M, D = partial.shape
     assert h.is_contiguous() and h.shape == (M, D) and (out is None or (out.is_contiguous() and out.shape == (M, D)))
-    check(lib().gar_splitk_residual_rmsnorm(dtype_code(h.dtype), ptr(partial), S, ptr(h), ptr(w), ptr(out), M, D, eps,
-                                            stream()), "gar_splitk_residual_rmsnorm")
+    _timed("splitk_reduce", partial.numel() * 4 + (2 + (out is not None)) * M * D * h.element_size(), lambda: check(
+        lib().gar_splitk_residual_rmsnorm(dtype_code(h.dtype), ptr(partial), S, ptr(h), ptr(w), ptr(out), M, D, eps,
+                                          stream()), "gar_splitk_residual_rmsnorm"))
     return h
 
 
@@ -163,6 +188,14 @@ def cls_pos_fill(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor):
     T, tokens, D = x.shape
     check(lib().gar_cls_pos_fill(dtype_code(x.dtype), ptr(x), ptr(cls), ptr(pos), T, tokens, D, stream()),
           "gar_cls_pos_fill")
+
+
+def tokens_add(x: torch.Tensor, add: torch.Tensor, token_offset: int):
+    """x[t, token_offset + p, :] += add[t, p, :] (modeling_perception_lm.py:195-196, ``x + mask_embeds...``)."""
+    T, tokens_out, D = x.shape
+    assert x.is_contiguous() and add.is_contiguous() and add.dtype == x.dtype and add.shape[0] == T and add.shape[2] == D
+    check(lib().gar_tokens_add(dtype_code(x.dtype), ptr(x), ptr(add), T, add.shape[1], tokens_out, token_offset, D, stream()),
+          "gar_tokens_add")
 
 
 def _rows(x):
@@ -329,12 +362,13 @@ def vit_v_transpose(v, Vt, T, N, H, hd, Npad):
           "gar_vit_v_transpose")
 
 
-def llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None):
+def llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, pos_dev, q_scale, left_pad=None,
+                 strip_order: bool = False):
     """``Kc``, ``Vc`` [B, Hkv, Smax, hd]. ``left_pad`` int32 [B] (device) or None: first real row of each sequence of a
-    left-padded batch."""
+    left-padded batch. ``strip_order``: the q / k head columns of ``qkv`` are in :func:`llm_qkv_weight_order`'s order."""
     check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vc), B, S,
-                                 Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), ptr(left_pad), q_scale, stream()),
-          "gar_llm_qkv_post")
+                                 Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), ptr(left_pad), q_scale, int(strip_order),
+                                 stream()), "gar_llm_qkv_post")
 
 
 def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev=None,
@@ -343,31 +377,50 @@ def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, caus
     instead of its transpose.
     ``kv_start`` int32 [B] (device) or None: first visible kv row per sequence (left-padded batch).
     ``kv_prefix`` = 1 (v_row_major, non-causal): kv row 0 is folded into the softmax's initial state (ViT cls token)."""
+    # algorithmic flops: QK^T + PV over the (query, key) pairs that exist — q_len x kv_len, or the causal triangle
+    pairs = (q_len * (q_len + 1) // 2 + q_len * (kv_len - q_len)) if causal else q_len * kv_len
+    kind = "attn_causal" if causal else "attn_full"
     if v_row_major:
-        check(lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
-                                       kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), int(kv_prefix),
-                                       stream()), "gar_attention_vrow")
+        _timed(kind, 0.0, lambda: check(
+            lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+                                     kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), int(kv_prefix),
+                                     stream()), "gar_attention_vrow"), flops=4.0 * B * Hq * hd * pairs)
         return
-    check(lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
-                              kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention")
+    _timed(kind, 0.0, lambda: check(
+        lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+                            kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention"),
+        flops=4.0 * B * Hq * hd * pairs)
 
 
-def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None):
-    check(lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
-                                     ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
-          "gar_attention_decode")
+def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None,
+                     q_stride: int = 0):
+    """``q_stride`` (elements between the query rows of consecutive (b, head); 0 = hd, the packed [B, Hq, hd] form): with
+    ``q = Q[:, :, S - 1]`` of a prefill's Q [B, Hq, Spad, hd] and ``q_stride = Spad * hd`` the last prompt row is read in place."""
+    # (bytes: the kv length lives in device memory; bench.py prices a launch at B * Hkv * kv_len * hd * 2 tensors * 2 B)
+    _timed("attn_decode", 0.0, lambda: check(
+        lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), int(q_stride), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
+                                   ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
+        "gar_attention_decode"))
 
 
 def attention_decode_qkv(qkv, cos, sin, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev, q_scale, max_splits, workspace,
-                         left_pad=None) -> bool:
+                         left_pad=None, strip_order: bool = False) -> bool:
     """llm_qkv_post (S = 1) + attention_decode in one launch: ``qkv`` [B, (Hq + 2 Hkv) hd] raw GEMM output of the step, the
     new key / value rows are appended to ``Kc`` / ``Vc`` at row pos_dev[0]. False (nothing launched) in parity mode."""
+    prof = KERNEL_TIMERS
+    timed = prof is not None and not torch.cuda.is_current_stream_capturing()
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib().gar_attention_decode_qkv(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Kc), ptr(Vc), ptr(O), B, Hq,
-                                        Hkv, hd, Smax, ptr(pos_dev), ptr(left_pad), q_scale, max_splits, ptr(workspace),
-                                        stream())
+                                        Hkv, hd, Smax, ptr(pos_dev), ptr(left_pad), q_scale, int(strip_order), max_splits,
+                                        ptr(workspace), stream())
     if rc == hip.ERR_UNSUPPORTED:
         return False
     check(rc, "gar_attention_decode_qkv")
+    if timed:
+        e1.record()
+        prof.append((KERNEL_PHASE + "attn_decode", 0.0, 0.0, e0, e1))
     return True
 
 
@@ -484,11 +537,15 @@ def argmax_workspace(B, V) -> int:
     return int(lib().gar_argmax_workspace(B, V))
 
 
-def input_check(input_ids, vocab: int, counts, n_rows: int, spans, span_len: int, has_box, flags):
-    """device-side input checks of generate(validate=False): ORs INPUT_* bits into ``flags`` (int32 [1])."""
+def input_check(input_ids, vocab: int, counts, n_rows: int, spans, span_len: int, has_box, flags, attn_mask=None):
+    """device-side input checks of generate(validate=False): ORs INPUT_* bits into ``flags`` (int32 [1]). ``attn_mask``: bool /
+    uint8 [B, S] generation mask; a row that is not left-padded sets INPUT_MASK_NOT_LEFT_PADDED."""
     B, S = input_ids.shape
-    check(lib().gar_input_check(ptr(input_ids), B, S, int(vocab), ptr(counts), int(n_rows), ptr(spans), spans.shape[1],
-                                int(span_len), ptr(has_box), ptr(flags), stream()), "gar_input_check")
+    if attn_mask is not None:
+        assert attn_mask.dtype in (torch.bool, torch.uint8) and attn_mask.is_contiguous() and tuple(attn_mask.shape) == (B, S)
+    check(lib().gar_input_check(ptr(input_ids), B, S, int(vocab), ptr(counts), int(n_rows), ptr(spans),
+                                0 if spans is None else spans.shape[1], int(span_len), ptr(has_box), ptr(flags), ptr(attn_mask),
+                                stream()), "gar_input_check")
 
 
 def counter_add(counters, delta: int):

@@ -34,7 +34,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 9
+#define GAR_ABI_VERSION 10
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -130,6 +130,11 @@ typedef struct gar_gemm_params {
  * q/k/v/o/gate/up/down + lm_head (modeling_gar.py:418-426 -> HF LlamaModel), and the two 14x14/stride-14
  * convolutions as one im2col GEMM (modeling_gar.py:326-328, modeling_perception_lm.py:194-196). */
 int gar_gemm(int dtype, const gar_gemm_params* p, gar_stream_t stream);
+/* 1 when gar_gemm runs `p` on the persistent 256 x 256 bf16 tile GEMM — the only kernel with the folded-norm epilogues
+ * (row_scale / row_stats) and the fused qkv forms — 0 otherwise; nothing is launched (ABI v10). The host plans a pass around
+ * those epilogues only after asking this predicate, so the conditions (>= 128 output tiles, N >= 256, 16-byte alignment,
+ * ldc / ldr % 8, operands < 4 GiB, epilogue / row_scale pairing) exist once, in the library. */
+int gar_gemm_tile_takes(int dtype, const gar_gemm_params* p);
 
 /* A1+A2+K2 input side: mask decode round((m+1)/2*255)->clamp[0,P]->(v!=P) (modeling_gar.py:315-327) and patch
  * extraction of both `pixel_values` and the binary mask into one GEMM operand:
@@ -158,6 +163,12 @@ int gar_patch_embed(int dtype, const void* pixel, const void* maskbin, const voi
 /* cls token row: x[t, 0, :] = cls + pos[0]   (timm Eva._pos_embed, via modeling_perception_lm.py:197) */
 int gar_cls_pos_fill(int dtype, void* x, const void* cls, const void* pos, int T, int tokens, int D,
                      gar_stream_t stream);
+/* x[t, token_offset + p, :] += add[t, p, :] for x [T, tokens_out, D], add [T, tokens_in, D] (D % 8 == 0): the reference's
+ * `x = x + mask_embeds.flatten(2).transpose(1, 2)` (modeling_perception_lm.py:195-196) for callers of
+ * mllm.get_image_features(pixel_values, mask_embeds=...) (modeling_gar.py:334-337) that computed the mask-embedding conv
+ * themselves; generate() folds that conv into the patch-embed GEMM instead (ABI v10). */
+int gar_tokens_add(int dtype, void* x, const void* add, int T, int tokens_in, int tokens_out, int token_offset, int D,
+                   gar_stream_t stream);
 
 /* nn.LayerNorm (norm_pre / norm1 / norm2 of the PE ViT) and HF LlamaRMSNorm. y may alias x.
  * ldx / ldy = row strides in elements (<= 0 means D). */
@@ -198,10 +209,13 @@ int gar_vit_v_transpose(int dtype, const void* V, void* Vt, int T, int N, int H,
  * If `pos_dev` != NULL the start position is read from device memory (pos_dev[0]) instead of pos0 (graph replay).
  * `left_pad` (device int32 [B] or NULL): a LEFT-PADDED batch as HF generation builds it from `attention_mask`
  * (modeling_gar.py:418-426 forwards it): sequence b's first real token sits at row left_pad[b]; a token keeps its row in
- * the cache and rotates by position (row - left_pad[b]) (HF: position_ids = cumsum(attention_mask) - 1). */
+ * the cache and rotates by position (row - left_pad[b]) (HF: position_ids = cumsum(attention_mask) - 1).
+ * `qk_strip_order` != 0 (ABI v10): the q / k head columns of `qkv` come in GAR_EPI_QKV_ROPE_LLM's strip order (head_dim 128:
+ * dims [0..31, 64..95, 32..63, 96..127]; natural for head_dim 64) — what a GEMM with the strip-ordered (folded) qkv weight,
+ * the only bf16 copy the host keeps, produces when the fused epilogue does not take the shape. v heads are natural. */
 int gar_llm_qkv_post(int dtype, const void* qkv, const float* cos, const float* sin, void* Q, void* Kc, void* Vc,
                      int B, int S, int Spad, int Hq, int Hkv, int hd, int Smax, int pos0, const int32_t* pos_dev,
-                     const int32_t* left_pad, float q_scale, gar_stream_t stream);
+                     const int32_t* left_pad, float q_scale, int qk_strip_order, gar_stream_t stream);
 
 /* Flash-style attention (replaces F.scaled_dot_product_attention in timm AttentionRope and flash-attn-2 /
  * eager attention in HF Llama, modeling_gar.py:40-43). Q [B,Hq,q_pad,hd] (pre-scaled by scale*log2e),
@@ -228,24 +242,28 @@ int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, v
 
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
  * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / V.
- * q [B,Hq,hd] pre-scaled; Kc, Vc [B,Hkv,Smax,hd] (gar_llm_qkv_post's caches); kv length = kv_len_dev[0] (device memory, so
+ * q: the query row of (b, head) starts at q + (b*Hq + head) * q_stride elements (q_stride = hd, or 0, for the packed
+ * [B,Hq,hd] form of a decode step; q_stride = Spad*hd with q = &Q[0][0][S-1][0] reads the LAST prompt row of a prefill's
+ * Q [B,Hq,Spad,hd] in place — the pruned last prefill layer, ABI v10), pre-scaled; Kc, Vc [B,Hkv,Smax,hd]
+ * (gar_llm_qkv_post's caches); kv length = kv_len_dev[0] (device memory, so
  * one captured hipGraph replays for every token); O [B, Hq*hd]. workspace >= gar_attention_decode_workspace() bytes.
  * GAR_F32 routes to gar_attention_vrow. bf16: head_dim 64 / 128, Smax * hd * 2 < 2 GiB (GAR_ERR_UNSUPPORTED otherwise).
  * `kv_start` (device int32 [B] or NULL): sequence b's keys are cache rows kv_start[b] .. kv_len - 1 (left-padded batch);
  * the kv splits divide that range. */
 int64_t gar_attention_decode_workspace(int B, int Hq, int hd, int max_splits);
-int gar_attention_decode(int dtype, const void* q, const void* Kc, const void* Vc, void* O, int B, int Hq, int Hkv,
-                         int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits,
+int gar_attention_decode(int dtype, const void* q, int64_t q_stride, const void* Kc, const void* Vc, void* O, int B, int Hq,
+                         int Hkv, int hd, int Smax, const int32_t* kv_len_dev, const int32_t* kv_start, int max_splits,
                          void* workspace, gar_stream_t stream);
 /* gar_llm_qkv_post (S = 1) and gar_attention_decode as ONE launch (ABI v9; bf16): `qkv` [B, (Hq+2Hkv)*hd] is the step's raw
  * qkv GEMM output. Every workgroup applies the half-split RoPE at position pos_dev[0] - left_pad[b] and q_scale to its query
  * heads while it loads them; the workgroup that owns the last kv tile of (b, kv head) rotates the new key, appends key and
  * value to cache row pos_dev[0] of Kc / Vc and attends over rows left_pad[b] .. pos_dev[0]. Same arithmetic, bit for bit,
  * as the two calls (HF: apply_rotary_pos_emb + DynamicCache.update + attention of one greedy step, modeling_gar.py:418-426).
- * GAR_ERR_UNSUPPORTED (nothing launched) for GAR_F32: parity mode keeps the two calls. */
+ * GAR_ERR_UNSUPPORTED (nothing launched) for GAR_F32: parity mode keeps the two calls.
+ * `qk_strip_order` as in gar_llm_qkv_post (ABI v10): the decode step's qkv GEMM runs on the strip-ordered folded weight. */
 int gar_attention_decode_qkv(int dtype, const void* qkv, const float* cos, const float* sin, void* Kc, void* Vc, void* O,
                              int B, int Hq, int Hkv, int hd, int Smax, const int32_t* pos_dev, const int32_t* left_pad,
-                             float q_scale, int max_splits, void* workspace, gar_stream_t stream);
+                             float q_scale, int qk_strip_order, int max_splits, void* workspace, gar_stream_t stream);
 
 /* PerceptionLMAdaptiveAvgPooling (modeling_perception_lm.py:47-60): per tile [g*g, C] -> [(g/2)^2, C], exact 2x2
  * mean. Input tile t starts at row t*in_tile_tokens + in_token_offset of x (lets the projector run over the
@@ -344,11 +362,14 @@ int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 /* The input checks of the reference's generate() without a host sync: image-token count vs feature rows (ValueError,
  * modeling_perception_lm.py:309-315), crop-token span length vs P*P (the splice of modeling_gar.py:404-411 would change
  * the sequence length), crop token present but no bbox (KeyError, modeling_gar.py:366), ids outside [0, vocab).
- * counts / spans: outputs of gar_placeholder_scan; has_box[b]: bit c set iff sample b has a bbox for crop token c.
- * ORs bits 1 / 2 / 4 / 8 into flags[0] (device int32, not cleared here). */
+ * counts / spans: outputs of gar_placeholder_scan; has_box[b]: bit c set iff sample b has a bbox for crop token c
+ * (counts NULL, or spans and has_box NULL: that group of checks is skipped — a text-only prompt).
+ * ORs bits 1 / 2 / 4 / 8 into flags[0] (device int32, not cleared here).
+ * attn_mask (nullable, ABI v10): uint8 / bool [B, S] generation mask (modeling_gar.py:418-426 forwards `attention_mask` to HF's
+ * generate); a row that is not 0...01...1 — not LEFT-padded: HF would continue it after its padding — sets bit 16. */
 int gar_input_check(const int64_t* input_ids, int B, int S, int64_t vocab, const int32_t* counts, int n_rows,
                     const int32_t* spans, int n_crop, int span_len, const int32_t* has_box, int32_t* flags,
-                    gar_stream_t stream);
+                    const uint8_t* attn_mask, gar_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -70,3 +70,38 @@ def test_no_gpu_means_loud_failure():
     import pytest
     with pytest.raises(hip.GarError, match="no GPU visible"):
         GARModel(GARConfig.tiny(), {}, torch.float32)
+
+
+def test_tile_gemm_predicate_is_the_librarys_own():
+    """gar_gemm_tile_takes (ABI v10): the host asks the LIBRARY which shapes the persistent tile GEMM takes before it plans a pass
+    around the folded-norm epilogues — no second copy of the conditions in Python (ADVICE r3 #2). Pure predicate: no device."""
+    from gar_amd import hip, ops
+    E = hip
+    # GAR-1B passes of the bench: ViT qkv / proj / fc1 / fc2 over 387 tiles, prefill over 26 sequences
+    M = 387 * 1025
+    assert ops.tile_gemm_takes(M, 3072, 1024, epilogue=E.EPI_QKV_ROPE, row_scale=True)
+    assert ops.tile_gemm_takes(M, 1024, 1024, epilogue=E.EPI_BIAS_SCALE_RES, row_stats=True)
+    assert ops.tile_gemm_takes(M, 4096, 1024, epilogue=E.EPI_BIAS_GELU, row_scale=True)
+    assert ops.tile_gemm_takes(26 * 4718, 16384, 2048, epilogue=E.EPI_SWIGLU, row_scale=True)
+    # fewer than 128 output tiles, a narrow N, an odd row pitch, a 4-GiB operand, a row_scale on a producer epilogue
+    assert not ops.tile_gemm_takes(1025, 1024, 1024)
+    assert not ops.tile_gemm_takes(400000, 128, 1024)
+    assert not ops.tile_gemm_takes(400000, 1024, 1024, ldc=1028)
+    assert not ops.tile_gemm_takes(400000, 1024, 8192, lda=8192)            # 400000 x 8192 x 2 B > 4 GiB
+    assert not ops.tile_gemm_takes(400000, 1024, 1024, epilogue=E.EPI_RES, row_scale=True)
+    assert not ops.tile_gemm_takes(400000, 1024, 1024, epilogue=E.EPI_BIAS, row_stats=True)
+    assert not ops.tile_gemm_takes(64, 128256, 2048)                        # decode rows go to the skinny kernel first
+
+
+def test_generation_options_filter():
+    """host logic of generate(): options that would change greedy tokens raise, their neutral values and the sampling-only knobs
+    (ignored by HF without do_sample) pass."""
+    import pytest
+    from gar_amd import hip
+    from gar_amd.modeling_gar import _refuse_non_greedy
+    ok = dict(num_beams=1, repetition_penalty=1.0, length_penalty=1.0, no_repeat_ngram_size=0, temperature=0.3, top_k=5)
+    _refuse_non_greedy(lambda k, d=None: ok.get(k, d))
+    for bad in (dict(num_beams=2), dict(repetition_penalty=1.1), dict(no_repeat_ngram_size=3), dict(bad_words_ids=[[1]]),
+                dict(min_new_tokens=4), dict(num_return_sequences=2), dict(penalty_alpha=0.6), dict(suppress_tokens=[5])):
+        with pytest.raises(hip.GarError, match=next(iter(bad))):
+            _refuse_non_greedy(lambda k, d=None, b=bad: b.get(k, d))

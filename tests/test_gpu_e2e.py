@@ -140,8 +140,127 @@ def test_mllm_helper_api(tiny):
     assert torch.equal(scattered.cpu(), want_emb)
     with pytest.raises(ValueError, match="do not match"):
         m.mllm.get_placeholder_mask(s["input_ids"], emb, image_features=feats[:-1])
-    with pytest.raises(hip.GarError, match="mask_embeds"):
-        m.mllm.get_image_features(s["pixel_values"], mask_embeds=torch.zeros(1))
+    with pytest.raises(hip.GarError, match="either mask_embeds"):
+        m.mllm.get_image_features(s["pixel_values"], mask_embeds=torch.zeros(1), global_mask_values=s["global_mask_values"])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_reference_generate_prologue_through_the_facade(tiny, dt):
+    """The body of the reference's GARModel.generate up to the feature replay (modeling_gar.py:315-346), statement by
+    statement, against THIS model's sub-API — mask decode in torch as the reference writes it, `model.mask_patch_embedding`,
+    `mllm.get_input_embeddings()`, `mllm.get_image_features(pixel_values=, mask_embeds=)`, `mllm.get_placeholder_mask`,
+    `masked_scatter` — equals what generate() builds internally (build_inputs_embeds before the replay rows are overwritten:
+    compared on the rows the replay does not touch) and the oracle's mask embeddings."""
+    from gar_amd.modeling_gar import GARModel
+    from oracle import gar_oracle as O
+    cfg, W, proc = tiny
+    s = _sample(cfg, proc, 2, dtype=dt)
+    self = GARModel(cfg, W, dt)
+    device = self.device
+    pixel_values, global_mask_values, input_ids = s["pixel_values"], s["global_mask_values"], s["input_ids"]
+    # ---- reference lines 315-346 ------------------------------------------------------------------------------------
+    pixel_values = pixel_values.to(device).to(self.mllm.dtype)
+    mask_values = torch.round((global_mask_values + 1.0) / 2.0 * 255.0).long().to(device)
+    mask_values = torch.clamp(mask_values, min=0, max=self.prompt_numbers)
+    assert mask_values.max() < self.prompt_numbers + 1 and mask_values.min() >= 0
+    mask_embeds = self.mask_patch_embedding((mask_values != self.prompt_numbers).to(self.mllm.dtype))
+    inputs_embeds = self.mllm.get_input_embeddings()(input_ids)
+    image_features = self.mllm.get_image_features(pixel_values=pixel_values, mask_embeds=mask_embeds)
+    image_features = image_features.to(inputs_embeds.device, dtype=inputs_embeds.dtype)
+    special_image_mask, _ = self.mllm.get_placeholder_mask(input_ids, inputs_embeds=inputs_embeds, image_features=image_features)
+    inputs_embeds = inputs_embeds.masked_scatter(special_image_mask, image_features)
+    # -----------------------------------------------------------------------------------------------------------------
+    v = cfg.mllm_config.vision_config
+    T = pixel_values.shape[0]
+    assert tuple(mask_embeds.shape) == (T, v.embed_dim, v.grid, v.grid)
+    Wd = {k: t.to(dt).float() for k, t in W.items()}
+    me_ref = O.mask_patch_embed(O.decode_mask_values(global_mask_values.float(), cfg.prompt_numbers), Wd["mask_patch_embedding.weight"])
+    tol = 1e-5 if dt == torch.float32 else 1.5e-2
+    assert _rel_l2(mask_embeds.float().cpu(), me_ref) < tol
+    # the fused form generate() runs (mask conv as K columns of the patch-embed GEMM)
+    fused_feats = self.get_image_features(s["pixel_values"], s["global_mask_values"]).clone()
+    assert _rel_l2(image_features, fused_feats) < (1e-5 if dt == torch.float32 else BF16_FEAT_TOL)
+    feats_ref = O.get_image_features(s["pixel_values"].float(), me_ref, Wd, cfg)
+    assert _rel_l2(image_features.float().cpu(), feats_ref) < (1e-4 if dt == torch.float32 else BF16_FEAT_TOL)
+    built = self.build_inputs_embeds(input_ids, fused_feats, s["bboxes"], s["aspect_ratios"], T)
+    crop = torch.zeros(input_ids.shape[1], dtype=torch.bool)
+    for tok in cfg.crop_tokens_ids:
+        crop |= (input_ids[0] == tok)
+    keep = ~crop
+    assert _rel_l2(inputs_embeds[0, keep.to(device)], built[0, keep.to(device)]) < (1e-5 if dt == torch.float32 else BF16_FEAT_TOL)
+    assert torch.equal(self.mask_patch_embedding.weight.float().cpu(), W["mask_patch_embedding.weight"].to(dt).float())
+
+
+def test_generation_options_that_would_change_greedy_tokens_are_refused(tiny):
+    """modeling_gar.py:418-426 forwards any GenerationConfig to HF; here only greedy search exists: beams / penalties raise
+    (they used to be ignored), sampling-only knobs without do_sample are accepted as HF accepts them."""
+    from gar_amd import hip
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    s = _sample(cfg, proc, 2)
+    m = GARModel(cfg, W, torch.float32)
+    base = m.generate(**s, generation_config=dict(max_new_tokens=3, do_sample=False, num_beams=1, repetition_penalty=1.0,
+                                                  temperature=0.7, top_p=0.9))
+    assert base.sequences.shape == (1, 3)
+    for bad in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(no_repeat_ngram_size=2), dict(min_new_tokens=5),
+                dict(bad_words_ids=[[3]]), dict(do_sample=True)):
+        with pytest.raises(hip.GarError):
+            m.generate(**s, generation_config=dict(max_new_tokens=3, **bad))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pruned_last_prefill_layer_equals_full_width(tiny, dt):
+    """PRUNE_LAST_PREFILL_LAYER: the last Llama layer of a prefill runs attention / o / gate-up / down for the last prompt row
+    only (what lm_head reads, modeling_perception_lm.py:545-552). Same tokens and logits as the full-width layer up to the
+    summation order of a different GEMM kernel; the KV caches — every row, all layers — are bit-identical (the qkv GEMM still
+    runs over all rows). Ragged (left-padded) batch included."""
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    ss = [_sample(cfg, proc, i, dtype=dt) for i in (2, 3, 5)]
+    batch = dict(input_ids=torch.cat([x["input_ids"] for x in ss]), pixel_values=torch.cat([x["pixel_values"] for x in ss]),
+                 global_mask_values=torch.cat([x["global_mask_values"] for x in ss]), bboxes=[x["bboxes"][0] for x in ss],
+                 aspect_ratios=torch.cat([x["aspect_ratios"] for x in ss]))
+    m = GARModel(cfg, W, dt)
+    assert m.PRUNE_LAST_PREFILL_LAYER
+    n = 6
+    pruned = m.generate(**batch, max_new_tokens=n, return_logits=True)
+    st = m._ws[m._llm_lru[-1]]
+    kc, vc = st["Kc"].clone(), st["Vc"].clone()
+    assert "att_last" in m._ws[("prefill",)]
+    m.PRUNE_LAST_PREFILL_LAYER = False
+    full = m.generate(**batch, max_new_tokens=n, return_logits=True, forced_tokens=pruned.sequences)
+    st = m._ws[m._llm_lru[-1]]
+    S = batch["input_ids"].shape[1]
+    assert torch.equal(kc[:, :, :, :S], st["Kc"][:, :, :, :S]) and torch.equal(vc[:, :, :, :S], st["Vc"][:, :, :, :S])
+    tol = 2e-5 if dt == torch.float32 else BF16_LOGIT_TOL
+    for j in range(n):
+        assert _rel_l2(pruned.logits[:, j], full.logits[:, j]) < tol, j
+    if dt == torch.float32:
+        assert torch.equal(pruned.sequences, full.sequences)
+
+
+def test_validate_false_flags_a_right_padded_attention_mask(tiny):
+    """generate(validate=False) takes left_pad from the mask's zero count without a host sync; gar_input_check looks at the
+    mask's FORM on the device: a row that is not 0...01...1 sets INPUT_MASK_NOT_LEFT_PADDED (validate=True raises on the host)."""
+    from gar_amd import hip
+    from gar_amd.modeling_gar import GARModel, INPUT_MASK_NOT_LEFT_PADDED
+    cfg, W, proc = tiny
+    s = _sample(cfg, proc, 2)
+    m = GARModel(cfg, W, torch.float32)
+    S = s["input_ids"].shape[1]
+    ok = torch.ones(1, S, dtype=torch.int64)
+    out = m.generate(**{**s, "attention_mask": ok}, max_new_tokens=2, validate=False)
+    assert int(out.input_flags.item()) == 0
+    right = ok.clone()
+    right[0, -3:] = 0
+    out = m.generate(**{**s, "attention_mask": right}, max_new_tokens=2, validate=False)
+    assert int(out.input_flags.item()) & INPUT_MASK_NOT_LEFT_PADDED
+    hole = ok.clone()
+    hole[0, 5] = 0                       # 1 1 1 1 1 0 1 ...: not a prefix of zeros
+    out = m.generate(**{**s, "attention_mask": hole}, max_new_tokens=2, validate=False)
+    assert int(out.input_flags.item()) & INPUT_MASK_NOT_LEFT_PADDED
+    with pytest.raises(hip.GarError, match="LEFT-padded"):
+        m.generate(**{**s, "attention_mask": right}, max_new_tokens=2)
 
 
 def test_batch_equals_singles_f32(tiny):
@@ -420,8 +539,8 @@ def test_bf16_folded_norms_gar1b_dims():
     s = _sample(cfg, proc, 3, 1024, 1024, dtype=torch.bfloat16)
     Wq = {k: v.to(torch.bfloat16).float() for k, v in W.items()}
     ref_seq, ref_logits = _oracle(Wq, cfg, s, 1, attn_impl="sdpa")
-    m = GARModel(cfg, W, torch.bfloat16)
-    assert m.FOLD_NORMS and "qkv_wf" in m.vblocks[0] and "gu_f" in m.layers[0]
+    m = GARModel(cfg, W, torch.bfloat16, keep_plain_weights=True)      # the un-folded copies: only kept for this A/B
+    assert m.FOLD_NORMS and "qkv_wf" in m.vblocks[0] and "gu_f" in m.layers[0] and "qkv_w" in m.vblocks[0] and "gu" in m.layers[0]
     folded = m.generate(**s, max_new_tokens=4, return_logits=True)
     assert "rstd" in m._ws[("vit",)] and "rstd" in m._ws[("prefill",)] and "h" not in m._ws[("vit",)]      # the folded path ran
     feats_f = m.get_image_features(s["pixel_values"], s["global_mask_values"]).clone()
@@ -465,7 +584,7 @@ def test_bf16_fused_llm_paths_gar1b_dims():
     batch = dict(input_ids=torch.cat([s["input_ids"]] * B), pixel_values=torch.cat([s["pixel_values"]] * B),
                  global_mask_values=torch.cat([s["global_mask_values"]] * B), bboxes=s["bboxes"] * B,
                  aspect_ratios=torch.cat([s["aspect_ratios"]] * B))
-    m = GARModel(cfg, W, torch.bfloat16)
+    m = GARModel(cfg, W, torch.bfloat16, keep_plain_weights=True)      # DECODE_GU_NORM_FOLDED = False needs a stand-alone norm path
     assert m.LLM_QKV_EPILOGUE and m.DECODE_ATTN_TAKES_QKV and m.DECODE_GU_NORM_FOLDED and not m.qkv_f_permuted
     fused = m.generate(**batch, max_new_tokens=n, return_logits=True)
     assert "qkv" not in m._ws[("prefill",)]                       # the [B*S, (Hq + 2 Hkv) hd] intermediate was never allocated
@@ -650,6 +769,25 @@ def test_replica_from_shapes_after_weight_copy(tiny):
         assert torch.equal(o0.sequences, o1.sequences) and torch.equal(o0.logits, o1.logits)
 
 
+@pytest.mark.parametrize("name", ["gar_1b", "gar_8b"])
+def test_bf16_device_weights_are_one_copy(name):
+    """bf16 keeps ONE copy of every weight (the norm-folded forms serve the tile GEMMs, the decode GEMVs and the small-shape
+    fallback): the prepared tensors a replica holds — and the RCCL broadcast moves — are within 3 % of the checkpoint's bytes
+    (round 3 kept plain + folded copies: +1.6 GB GAR-1B, +11 GB GAR-8B)."""
+    from gar_amd import GARConfig
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.weights import weight_shapes
+    cfg = getattr(GARConfig, name)()
+    ckpt = sum(int(torch.tensor(s).prod()) for s in weight_shapes(cfg).values()) * 2
+    m = GARModel.from_shapes(cfg, torch.bfloat16)
+    held = sum(t.numel() * t.element_size() for t in m.weight_tensors())
+    print(f"{name}: checkpoint {ckpt / 2**30:.2f} GiB, prepared device weights {held / 2**30:.2f} GiB ({held / ckpt - 1:+.2%})")
+    assert "qkv_w" not in m.vblocks[0] and "gu" not in m.layers[0] and "qkv" not in m.layers[0]
+    assert abs(held / ckpt - 1) < 0.03
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_f32_parity_gar1b_dims_max_tiles_one_layer():
     """PLM's default max_num_tiles=36 (6x6 canvas -> 37 tiles, S ~ 9.8k) at GAR-1B shapes with one
     layer each: the largest single-region configuration, f32 token parity with the oracle."""
@@ -787,6 +925,63 @@ def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert torch.equal(free_g.sequences, free_e.sequences)
 
 
+def test_bench_configuration_bf16_vs_f32_teacher_forced_64_regions():
+    """Parity AT THE CONFIGURATION bench.py TIMES: full-depth GAR-1B, B = 64 DISTINCT synthetic regions in
+    one generate — the planner's default passes (387 / 383 / 318 image tiles, 26 / 26 / 12 sequences), the 16 < B <= 64 decode
+    schedule (norm-folded GEMVs, split-K `down` + reduce, single-split decode attention at S ~ 4.7k) replayed from the hipGraph,
+    the pruned last prefill layer — bf16 teacher-forced on the f32 HIP run of the SAME batch (itself within 1e-5 of the CPU oracle
+    at B = 1, test_full_depth_...): per-row, per-step relative L2 of the logits, top-1 agreement over all 64 x 64 steps, and
+    every disagreement at an f32 top-2 margin inside the measured bf16 logit error — the B = 1 test's assertions, at B = 64."""
+    from gar_amd import GARConfig
+    from gar_amd.eval_dataset import SingleRegionCaptionDataset
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b()
+    W = synthetic_weights(cfg)
+    B, NT = 64, 64
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16).use_gpu_preprocessing("cuda:0", torch.float32)
+    ss = [SingleRegionCaptionDataset(synthetic_image(700 + i), synthetic_mask(700 + i), proc, data_dtype=torch.float32,
+                                     device="cuda:0")[0] for i in range(B)]
+    batch = dict(input_ids=torch.cat([x["input_ids"] for x in ss]), pixel_values=torch.cat([x["pixel_values"] for x in ss]),
+                 global_mask_values=torch.cat([x["global_mask_values"] for x in ss]), bboxes=[x["bboxes"][0] for x in ss],
+                 aspect_ratios=torch.cat([x["aspect_ratios"] for x in ss]))
+    del ss
+    assert batch["pixel_values"].shape[0] == 17 * B
+    m32 = GARModel(cfg, W, torch.float32)
+    o32 = m32.generate(**batch, max_new_tokens=NT, return_logits=True)
+    seq32 = o32.sequences.clone()
+    lg32 = o32.logits                                        # [B, NT, V] fp32 on the device (2.1 GB)
+    assert len({tuple(r) for r in seq32.cpu().tolist()}) == B           # 64 different regions -> 64 different captions
+    del m32, o32
+    torch.cuda.empty_cache()
+    bb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    m16 = GARModel(cfg, W, torch.bfloat16)
+    S = batch["input_ids"].shape[1]
+    plan_v, plan_l = m16._plan_passes(B, 17, S)
+    assert len(plan_v) > 1 and len(plan_l) > 1 and sum(plan_v) == 17 * B and sum(plan_l) == B      # the planner's passes, not one chunk
+    o16 = m16.generate(**bb, max_new_tokens=NT, return_logits=True, forced_tokens=seq32)
+    assert "down_partial" in m16._ws[("decode", B)] and m16._graphs                  # the B = 64 schedule, replayed from the graph
+    lg16 = o16.logits
+    rel = ((lg16 - lg32).double().norm(dim=-1) / lg32.double().norm(dim=-1))         # [B, NT]
+    agree = (o16.sequences == seq32)
+    rate = float(agree.float().mean())
+    err_row = (lg16 - lg32).abs().amax(dim=(1, 2))                                   # [B] max |dlogit| of each region's caption
+    top2 = lg32.topk(2, -1).values
+    margins = top2[..., 0] - top2[..., 1]                                            # [B, NT]
+    print(f"B = 64 full depth bf16 vs f32 (teacher forced, {NT} tokens x {B} regions): top-1 agreement {rate:.4f} (worst region "
+          f"{float(agree.float().mean(1).min()):.3f}), rel-L2 first token mean {float(rel[:, 0].mean()):.3e} / worst {float(rel[:, 0].max()):.3e}, "
+          f"worst of all steps {float(rel.max()):.3e}, max|dlogit| {float(err_row.max()):.3e}")
+    assert float(rel.max()) < FULL_DEPTH_BF16_REL_L2, float(rel.max())
+    bad = (~agree) & (margins >= 2 * err_row[:, None])
+    assert not bool(bad.any()), bad.nonzero().tolist()[:8]
+    assert rate >= 0.85, rate
+    # the same batch through eager launches: the graph replays exactly these kernels
+    e16 = m16.generate(**bb, max_new_tokens=8, use_graph=False, forced_tokens=seq32)
+    assert torch.equal(e16.sequences, o16.sequences[:, :8])
+
+
 @pytest.mark.parametrize("max_num_tiles,canvas", [(16, (4, 4)), (8, (3, 2))])
 def test_config0_demo_asset_f32_parity(golden_dir, max_num_tiles, canvas):
     """BASELINE configs[0]: assets/demo_image_1.png (1024 x 770 RGBA) + demo_mask_1.png through the sample builder the
@@ -871,6 +1066,7 @@ def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert max(rel) < FULL_DEPTH_8B_BF16_REL_L2, max(rel)
     for j in (~agree).nonzero().flatten().tolist():
         assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
+    assert rate >= 0.80, rate          # measured 0.875 (round 3); a regression in the head_dim 96 / 128 kernels must not hide below it
     free_g = m16.generate(**sb, max_new_tokens=8)
     free_e = m16.generate(**sb, max_new_tokens=8, use_graph=False)
     assert torch.equal(free_g.sequences, free_e.sequences)

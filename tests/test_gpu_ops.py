@@ -1216,6 +1216,105 @@ def test_fused_llm_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, hd, Hq, Hkv, B,
     close(V1[:, :, p0:p0 + S], xv, dt, extra=1.5)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd", [64, 128])
+def test_llm_qkv_post_and_decode_attention_take_strip_ordered_heads(dev, dt, hd):
+    """ABI v10: bf16 keeps ONE copy of the Llama qkv weight — folded, rows in GAR_EPI_QKV_ROPE_LLM's strip order — so the
+    un-fused consumers of its product (gar_llm_qkv_post for shapes the fused epilogue does not take, gar_attention_decode_qkv in
+    every decode step) read q / k head columns in that order: same outputs, bit for bit, as the natural order."""
+    from gar_amd import ops
+    B, S, Hq, Hkv = 3, 70, 4, 2
+    Wd = (Hq + 2 * Hkv) * hd
+    Smax, Spad = 128, 128
+    order = ops.llm_qkv_weight_order(hd, Hq, Hkv)
+    assert bool((order != torch.arange(Wd)).any()) == (hd == 128)
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = (pos[:, None] * inv[None]).to(dev)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    qs = hd ** -0.5 * 1.4426950408889634
+    x = q(rnd(B * S, Wd, seed=140), dt)
+    xn, xp = x.to(dev, dt), x[:, order].contiguous().to(dev, dt)
+    lp = torch.tensor([0, 5, 11], dtype=torch.int32, device=dev)
+    outs = []
+    for src, strip in ((xn, False), (xp, True)):
+        Q = torch.zeros(B, Hq, Spad, hd, dtype=dt, device=dev)
+        K, V = (torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev) for _ in range(2))
+        ops.llm_qkv_post(src, cos, sin, Q, K, V, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, qs, left_pad=lp, strip_order=strip)
+        outs.append((Q, K, V))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # one decode step on top of those caches: two-call form and the fused launch, natural vs strip order
+    x1 = q(rnd(B, Wd, seed=141), dt)
+    counters = torch.tensor([S, S + 1], dtype=torch.int32, device=dev)
+    res = []
+    for src, strip in ((x1.to(dev, dt), False), (x1[:, order].contiguous().to(dev, dt), True)):
+        Q1 = torch.empty(B, Hq, 1, hd, dtype=dt, device=dev)
+        K, V = outs[0][1].clone(), outs[0][2].clone()
+        ops.llm_qkv_post(src, cos, sin, Q1, K, V, B, 1, 1, Hq, Hkv, hd, Smax, 0, counters[0:1], qs, left_pad=lp, strip_order=strip)
+        ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, 2), dtype=torch.uint8, device=dev)
+        o2 = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
+        ops.attention_decode(Q1, K, V, o2, B, Hq, Hkv, hd, Smax, counters[1:2], 2, ws, kv_start=lp)
+        Kf, Vf, o3 = outs[0][1].clone(), outs[0][2].clone(), torch.full_like(o2, float("nan"))
+        took = ops.attention_decode_qkv(src, cos, sin, Kf, Vf, o3, B, Hq, Hkv, hd, Smax, counters[0:1], qs, 2, ws, left_pad=lp,
+                                        strip_order=strip)
+        assert took == (dt == torch.bfloat16)
+        if took:
+            assert torch.equal(o3, o2) and torch.equal(Kf, K) and torch.equal(Vf, V)
+        res.append((Q1, K, V, o2))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("S", [70, 257])
+def test_decode_attention_reads_the_last_prompt_row_in_place(dev, dt, hd, S):
+    """gar_attention_decode(q_stride=): the query of (b, head) is row S - 1 of a prefill's Q [B, Hq, Spad, hd], read where the
+    qkv GEMM left it (the pruned last prefill layer) — equal, bit for bit, to the packed [B, Hq, hd] copy of those rows, and to
+    row S - 1 of the causal prefill attention within the dtype's tolerance. Left-padded rows included."""
+    from gar_amd import ops
+    B, Hq, Hkv = 3, 4, 2
+    Wd = (Hq + 2 * Hkv) * hd
+    Smax = (S + 8 + 63) // 64 * 64
+    Spad = (S + 63) // 64 * 64
+    pos = torch.arange(Smax, dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = (pos[:, None] * inv[None]).to(dev)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    qs = hd ** -0.5 * 1.4426950408889634
+    qkv = q(rnd(B * S, Wd, seed=150), dt).to(dev, dt)
+    lp = torch.tensor([0, 9, 40], dtype=torch.int32, device=dev)
+    Q = torch.zeros(B, Hq, Spad, hd, dtype=dt, device=dev)
+    Kc, Vc = (torch.zeros(B, Hkv, Smax, hd, dtype=dt, device=dev) for _ in range(2))
+    ops.llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, 0, None, qs, left_pad=lp)
+    full = torch.empty(B * S, Hq * hd, dtype=dt, device=dev)
+    ops.attention(Q, Kc, Vc, full, B, Hq, Hkv, hd, S, Spad, S, Smax, causal=True, kv_start=lp, v_row_major=True)
+    kvl = torch.tensor([S], dtype=torch.int32, device=dev)
+    for nsplit in (1, 4):
+        ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, nsplit), dtype=torch.uint8, device=dev)
+        o_in = torch.full((B, Hq * hd), float("nan"), dtype=dt, device=dev)
+        ops.attention_decode(Q[:, :, S - 1], Kc, Vc, o_in, B, Hq, Hkv, hd, Smax, kvl, nsplit, ws, kv_start=lp, q_stride=Spad * hd)
+        o_pk = torch.full_like(o_in, float("nan"))
+        ops.attention_decode(Q[:, :, S - 1].contiguous(), Kc, Vc, o_pk, B, Hq, Hkv, hd, Smax, kvl, nsplit, ws, kv_start=lp)
+        assert torch.equal(o_in, o_pk)
+        close(o_in, full.view(B, S, Hq * hd)[:, S - 1].float().cpu(), dt, extra=2.0)
+
+
+def test_tokens_add(dev):
+    """gar_tokens_add: x[t, off + p, :] += add[t, p, :] (the reference's `x + mask_embeds.flatten(2).transpose(1, 2)`)."""
+    from gar_amd import ops
+    for dt in DT:
+        T, tin, off, D = 3, 37, 1, 64
+        x0 = q(rnd(T, tin + off, D, seed=160), dt)
+        add = q(rnd(T, tin, D, seed=161), dt)
+        x = x0.to(dev, dt).clone()
+        ops.tokens_add(x, add.to(dev, dt), off)
+        want = x0.clone()
+        want[:, off:] = q(x0[:, off:] + add, dt)
+        assert torch.equal(x.float().cpu(), want)
+
+
 def test_fused_llm_qkv_rope_start_position_from_device_memory(dev):
     """qkv_pos_dev overrides qkv_pos0 (graph replay convention of gar_llm_qkv_post)."""
     from gar_amd import ops
