@@ -422,6 +422,26 @@ def main(argv=None, runtime=None):
         model.generate(**make_batch(0), **{**gen_kw, "max_new_tokens": args.decode_probe_steps + 1, "use_graph": False})
         rt.sync()
         probe, ops.KERNEL_TIMERS = [t for t in ops.KERNEL_TIMERS if t[0].startswith("decode:")], None
+    # ---- the decode loop by itself (what the reference's callers wait for per token at batch 1): one more generate after the
+    # timed region, host clock around generate_finish() only — the hipGraph replays of new_tokens - 1 steps
+    decode_loop = None
+    if args.new_tokens > 1 and hasattr(model, "generate_finish"):
+        pend = model.generate_begin(**make_batch(0), **gen_kw)
+        rt.sync()
+        td = time.perf_counter()
+        model.generate_finish(pend)
+        rt.sync()
+        td = time.perf_counter() - td
+        tcfg = cfg.mllm_config.text_config
+        wbytes = sum(t.numel() * t.element_size() for ly in model.layers for t in ly.values()) + \
+            model.lm_head.numel() * model.lm_head.element_size()
+        kvb = B * (S + args.new_tokens / 2.0) * tcfg.num_hidden_layers * 2 * tcfg.num_key_value_heads * tcfg.head_dim * 2
+        decode_loop = {"ms_per_token": td / (args.new_tokens - 1) * 1e3, "steps": args.new_tokens - 1, "sequences": B,
+                       "hipgraph": not args.no_graph,
+                       "streamed_bytes_per_token": wbytes + kvb, "weight_bytes_per_token": wbytes, "kv_bytes_per_token": kvb,
+                       "hbm_frac": (wbytes + kvb) / (td / (args.new_tokens - 1)) / 1e9 / PEAK_HBM_GBS,
+                       "note": "host clock around generate_finish (decode steps only) of one extra batch after the timed region; "
+                               "bytes = every layer's weights + lm_head once per token + K and V rows of every sequence"}
     # ---- roofline of the dominant kernel (bf16 tile GEMM), live HIP-event timing over the timed region ---------------
     def fold(ts):
         agg_ = {}
@@ -570,6 +590,8 @@ def main(argv=None, runtime=None):
             hbm_entry("splitk_res_rms_kernel, decode steps (split-K reduce + residual (+ final RMSNorm))", nb, sec, cnt,
                       sec / nsteps_probe * dec_steps / step_s, us_per_decode_step=sec / nsteps_probe * 1e6, note=probe_note)
         tot = sum(a[2] for a in pagg.values())
+        if decode_loop:
+            line["decode_loop"] = decode_loop
         line["decode_step_probe"] = {"eager_us_per_step_sum_of_kernels": tot / nsteps_probe * 1e6, "steps": nsteps_probe,
                                      "kernels_per_step": sum(a[3] for a in pagg.values()) / nsteps_probe}
     covered = sum(v.get("time_share_of_step", 0.0) for k, v in other.items() if not k.startswith("roi_replay_inplace_kernel alone"))

@@ -30,6 +30,27 @@ __device__ __forceinline__ f32x16 zero16_c() {
     return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 }
 
+// 2^x for x <= 0 on the FMA pipe, two elements per instruction where a packed form exists: t = x + 1.5 * 2^23 rounds x to the
+// nearest integer n in t's low mantissa bits; f = x - n in [-0.5, 0.5]; 2^f by a degree-3 polynomial (|rel err| < 1.1e-4, bf16
+// rounds P at 3.9e-3); the result's exponent += n by an integer add of (bits(t) << 23).
+__device__ __forceinline__ f32v2_t exp2_poly2(f32v2_t x) {
+    x[0] = __builtin_amdgcn_fmed3f(x[0], -125.0f, 0.0f);
+    x[1] = __builtin_amdgcn_fmed3f(x[1], -125.0f, 0.0f);
+    const f32v2_t magic = {12582912.0f, 12582912.0f};
+    const f32v2_t t = x + magic;
+    const f32v2_t n = t - magic;
+    const f32v2_t f = x - n;
+    const f32v2_t c3 = {0.05590050f, 0.05590050f}, c2 = {0.24015480f, 0.24015480f}, c1 = {0.69313330f, 0.69313330f},
+                  one = {1.0f, 1.0f};
+    f32v2_t p = __builtin_elementwise_fma(f, c3, c2);
+    p = __builtin_elementwise_fma(p, f, c1);
+    p = __builtin_elementwise_fma(p, f, one);
+    f32v2_t r;
+    r[0] = __uint_as_float(__float_as_uint(p[0]) + (__float_as_uint(t[0]) << 23));
+    r[1] = __uint_as_float(__float_as_uint(p[1]) + (__float_as_uint(t[1]) << 23));
+    return r;
+}
+
 template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 128 ? ((row >> 1) & 7) : (row & 15); }
 
 // VROW: V arrives row-major [kv][HD] — the layout the fused qkv GEMM epilogue writes, no transpose pass — is
@@ -39,6 +60,17 @@ template <int RS> __device__ __forceinline__ int key_of(int row) { return RS == 
 // consecutive kv of one d that the MFMA fragment wants. The 16-byte chunks of a V row are XOR-ed with 4 ((kv >> 1) & 1):
 // the four rows of a block (128 B apart) then cover all 64 banks exactly once for a 32-lane half.
 typedef short tr4_t __attribute__((ext_vector_type(4)));
+#ifndef ATTN_POLY_EXP      /* n > 0 (even): the first n of every 16 scores of a block are exponentiated on the FMA pipe — Cody-Waite range
+                              reduction (magic-number rounding) + degree-3 polynomial in packed fp32 + exponent add — instead of
+                              v_exp_f32, so that the transcendental unit and the FMA pipe share the softmax (VERDICT r3 #1b) */
+#define ATTN_POLY_EXP 0
+#endif
+#ifndef ATTN_KPRE          /* 1: the tile's K fragments are all read before the first QK^T MFMA */
+#define ATTN_KPRE 0
+#endif
+#ifndef ATTN_VPRE          /* 1: the tile's V fragments are read before the softmax arithmetic (VROW only), consumed after it */
+#define ATTN_VPRE 0
+#endif
 #ifndef ATTN_PK_SUM        /* n > 0: row sums of P in n packed-fp32 partial chains (v_pk_add_f32) instead of 32 scalar adds per tile */
 #define ATTN_PK_SUM 0
 #endif
@@ -237,6 +269,22 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             const char* vs = ks + KT;
             f32x16 s[2];
             auto qk = [&]() {
+#if ATTN_KPRE
+                // all K fragments of the tile in flight before the first MFMA (the compiler otherwise re-uses one register quad
+                // and waits for every ds_read in front of its MFMA: eight exposed LDS latencies per tile and wave)
+                bf16x8 kfa[2][NKD];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int kd = 0; kd < NKD; ++kd)
+                        kfa[blk][kd] = *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kd = 0; kd < NKD; ++kd)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+                        s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[blk][kd], qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
+#else
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
@@ -246,8 +294,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                         s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
                     }
                 }
+#endif
             };
             qk();
+#if ATTN_VPRE
+            bf16x8 vfa[NDB][2][2];
+            if (VROW) {
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16) * KRS + (vtr ^ (d << 6))));
+                            const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) tr4_t*)(vs + (blk * 32 + tt * 16 + 4) * KRS + (vtr ^ (d << 6))));
+                            vfa[d][blk][tt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             TLA(2)
             // register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
             const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);   // wave-uniform
@@ -264,6 +331,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                     float p[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
+#if ATTN_POLY_EXP
+                        if (r < ATTN_POLY_EXP) {
+                            if ((r & 1) == 0) {
+                                const f32v2_t e2 = exp2_poly2(f32v2_t{NEGM ? s[blk][r] : s[blk][r] - m_sub,
+                                                                      NEGM ? s[blk][r + 1] : s[blk][r + 1] - m_sub});
+                                p[r] = e2[0];
+                                p[r + 1] = e2[1];
+                            }
+                        } else
+#endif
                         p[r] = __builtin_amdgcn_exp2f(NEGM ? s[blk][r] : s[blk][r] - m_sub);
 #if !ATTN_PK_SUM
                         if (!ATTN_MFMA_ROWSUM) ps += p[r];
@@ -384,6 +461,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         bf16x8 vf;
+#if ATTN_VPRE
+                        if (VROW) {
+                            vf = vfa[d][blk][tt];
+                        } else
+#endif
                         if (VROW) {
                             // this lane's chunk of its group's [4 kv][16 d] block: kv row (blk*32 + tt*16 + 8h) + (i >> 2) (+4),
                             // d columns d*32 + 16 ((lane >> 4) & 1) + 4 (i & 3);  i = lane & 15.  vtr = byte offset of (kv row i >> 2 of

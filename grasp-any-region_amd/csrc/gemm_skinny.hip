@@ -31,15 +31,19 @@
 // NORM: 0 none; 1 RMSNorm prologue with its gain (p.norm_w): x*g is the operand, sum x^2 accumulated on the VALU; 2 RMSNorm with
 // the gain folded into W (p.norm_folded): the operand is x itself and the row sums of squares come off the matrix pipe — one
 // extra MFMA pair per row tile and K step, x_tile x_tile^T, whose DIAGONAL is sum_k x[m][k]^2 (HBM-bound kernel: the pipe idles)
-template <int EPI, int NT, int MT, int NORM, bool STAGED>
+// ROWS = 8 (NT == 1 only): a block owns EIGHT weight rows instead of sixteen — the upper half of its MFMA tile is never staged
+// nor stored — so that a narrow output (N = 2048: 128 sixteen-row tiles) still gives every CU a block: Llama's o / down at
+// M <= 16 stream from 256 CUs instead of 128 (tools/bench_skinny.py, round 4).
+template <int EPI, int NT, int MT, int NORM, bool STAGED, int ROWS = 16>
 __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
+    static_assert(ROWS == 16 || (ROWS == 8 && NT == 1), "half tiles are built for one weight tile per block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* red = reinterpret_cast<float*>(smem);                  // [nw][NT*MT][64][4]
     float* red_ss = red + nw * NT * MT * 256;                     // [nw][MT][16]
     const int frow = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16 * NT;
+    const int n0 = blockIdx.x * ROWS * NT;
     const bf16_t* W = (const bf16_t*)p.W;
     const bf16_t* X = (const bf16_t*)p.A;
     const bf16_t* Gw = (const bf16_t*)p.norm_w;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
     }
     const bf16_t* wp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)min(n0 + t * 16 + frow, p.N - 1) * p.ldw + fq * 16;
+    for (int t = 0; t < NT; ++t) wp[t] = W + (int64_t)min(n0 + t * 16 + (ROWS == 8 ? (frow & 7) : frow), p.N - 1) * p.ldw + fq * 16;
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -103,7 +107,8 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < (ROWS == 8 ? 1 : 2); ++i)      // ROWS == 8: rows 8..15 of the LDS tile keep whatever they hold (their
+                                                                 // MFMA output rows are never stored; rows do not mix)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(slot + t * 2048 + i * 1024), 16,
                                                          voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, SK_W_AUX);
     };
@@ -127,7 +132,8 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
     auto step_staged = [&](int ks, bool more) {
         const int k0 = ks * 64;
         if (WD > 1 && ks + WD - 1 < ks1 && ks > ks0) {
-            if (NT == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (NT == 1 && ROWS == 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (NT == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -294,6 +300,7 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
                 for (int r = 0; r < 4; ++r) v[t][r] *= rstd;
         }
         if (m >= p.M) continue;
+        if (ROWS == 8 && fq >= 2) continue;            // weight rows 8..15 of a half tile belong to the next block
         if (EPI == GAR_EPI_NONE && nsplit > 1) {
             float* part = reinterpret_cast<float*>(p.partial) + ((int64_t)blockIdx.y * p.M + m) * p.N;
 #pragma unroll
@@ -321,9 +328,9 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
     }
 }
 
-template <int EPI, int MT, int NT>
+template <int EPI, int MT, int NT, int ROWS = 16>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
-    const int nb = (p.N + 16 * NT - 1) / (16 * NT);
+    const int nb = (p.N + ROWS * NT - 1) / (ROWS * NT);
     const int nsplit = (EPI == GAR_EPI_NONE && p.split_k > 1) ? p.split_k : 1;
     const int ksteps = p.K / 64 / nsplit;
     // buffer descriptors address W / x with 32-bit byte offsets (larger operands take the per-lane fragment loads)
@@ -333,18 +340,18 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     static gar_once_per_device attr_once;
     attr_once.run([&] {
         if constexpr (NT <= 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, true, ROWS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 1, false, ROWS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
         }
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, true, ROWS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 0, false, ROWS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, true, ROWS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, NT, MT, 2, false, ROWS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
     });
     // enough waves to cover HBM latency (>= ~2048 chip-wide), >= 2 K steps per wave, LDS (merge buffer, and the
@@ -360,7 +367,7 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     while (nw < max_nw && nb * nsplit * nw < 2048 && ksteps / (nw * 2) >= 2 && lds_for(nw * 2) <= MAXLDS) nw *= 2;
     const int lds = lds_for(nw);
 #define LAUNCH_SK(NORM_, ST_) \
-    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_>), dim3(nb, nsplit), dim3(nw * 64), lds, s, p)
+    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, NT, MT, NORM_, ST_, ROWS>), dim3(nb, nsplit), dim3(nw * 64), lds, s, p)
     if constexpr (NT <= 2) {
         if (p.norm_w) {
             if (staged) LAUNCH_SK(1, true); else LAUNCH_SK(1, false);
@@ -382,7 +389,17 @@ template <int EPI>
 static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
     constexpr int NT0 = (EPI == GAR_EPI_SWIGLU) ? 2 : 1;
     constexpr int wide = 8192;      // output width from which M > 16 uses 4 weight tiles per block (tools/bench_skinny.py)
-    if (p.M <= 16) launch_skinny<EPI, 1, NT0>(p, s);
+#ifndef SK_HALF_MAX_N       /* widest output that takes 8-row half tiles at M <= 16 (0 = never) */
+#define SK_HALF_MAX_N 2048
+#endif
+    if (p.M <= 16) {
+        // a narrow output: 8-row half tiles so that N / 8 blocks (256 for N = 2048) cover the chip instead of N / 16
+        if (NT0 == 1 && p.N <= SK_HALF_MAX_N && p.N % 8 == 0 && p.split_k <= 1) {
+            if constexpr (NT0 == 1) launch_skinny<EPI, 1, 1, 8>(p, s);
+        } else {
+            launch_skinny<EPI, 1, NT0>(p, s);
+        }
+    }
     else if (p.M <= 32) {
         if (p.N >= wide && !p.norm_w) launch_skinny<EPI, 2, 4>(p, s); else launch_skinny<EPI, 2, NT0>(p, s);
     } else {

@@ -299,7 +299,12 @@ class GARModel:
     DECODE_ATTN_TAKES_QKV = True  # bf16: the decode attention launch does llm_qkv_post's work (gar_attention_decode_qkv)
     VIT_CLS_KEY_FOLD = True       # bf16: the cls key / value row enters the ViT attention through the initial softmax state
     VIT_V_ROW_MAJOR = True        # bf16: v leaves the qkv GEMM head-major, gar_attention_vrow transposes on its LDS reads
-    DECODE_ATTN_BLOCKS = 512      # target (split, kv head, batch) workgroups of the split-KV decode attention (2048 waves)
+    # split-KV decode attention: kv splits per (sequence, kv head) so that ~DECODE_ATTN_BLOCKS workgroups exist, at most
+    # DECODE_ATTN_MAX_SPLITS — measured optimum at kv ~ 4.75k (tools/bench_decode_attn.py, hipGraph replays, round 4): B = 1 / 2 / 4:
+    # 8 splits (12.0 us against 21.9 with the 64 splits a 512-block target gave: more splits = a longer combine launch and more
+    # partial-block overhead than bytes in flight are worth), B = 8: 2-4, B = 12: 2, B >= 16: 1 (no combine launch)
+    DECODE_ATTN_BLOCKS = 192
+    DECODE_ATTN_MAX_SPLITS = 8
     FUSE_NORM_MAX_BATCH = 16      # largest decode batch that keeps `down` un-split (f32 / plain weights: RMSNorm in the GEMV prologue)
     # The LAST Llama layer of a prefill computes attention / o / gate-up / down for the last prompt row of every sequence only:
     # the head reads nothing else (modeling_perception_lm.py:545-552, `lm_head(hidden_states[:, slice_indices, :])`) and the
@@ -956,7 +961,7 @@ class GARModel:
         ffl = self._buf(key, "ff_last", (B, F))
         kv_len = st["counters"][3:4]                    # scratch word of the counters: the prompt length, for the kernel's kv_len_dev
         kv_len.fill_(S)
-        nsplit = max(1, min(64, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
+        nsplit = max(1, min(self.DECODE_ATTN_MAX_SPLITS, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws_last", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.attention_decode(Q[:, :, S - 1], Kc, Vc, attl, B, Hq, Hkv, hd, Smax, kv_len, nsplit, dws, kv_start=lp,
                              q_stride=Spad * hd)
@@ -1014,8 +1019,7 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         pos_dev, kvlen_dev = st["counters"][0:1], st["counters"][1:2]
-        # enough (split, kv head, batch) 4-wave blocks to cover the chip: ~512 blocks = 2048 waves
-        nsplit = max(1, min(64, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
+        nsplit = max(1, min(self.DECODE_ATTN_MAX_SPLITS, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
         bf16 = self.dtype == torch.bfloat16

@@ -16,13 +16,17 @@ def main():
     Hq, Hkv, Smax, kv = 32, 8, 4800, 4750
     hd = int(os.environ.get("HD", "64"))    # 64: GAR-1B, 128: GAR-8B
     L = 4                                   # distinct caches so the stream comes from HBM
-    for B in (16, 64):
+    batches = [int(x) for x in os.environ.get("BATCHES", "16,64").split(",")]
+    splits = [int(x) for x in os.environ.get("NSPLITS", "1,2,4").split(",")]
+    if os.environ.get("L"):
+        L = int(os.environ["L"])
+    for B in batches:
         Kc = [torch.randn(B, Hkv, Smax, hd, device=dev).to(dt) for _ in range(L)]
         Vc = [torch.randn(B, Hkv, Smax, hd, device=dev).to(dt) for _ in range(L)]       # same bytes in either V layout
         q = torch.randn(B, Hq, hd, device=dev).to(dt)
         O = torch.empty(B, Hq * hd, device=dev, dtype=dt)
         kvl = torch.tensor([kv], dtype=torch.int32, device=dev)
-        for ns in (1, 2, 4):
+        for ns in splits:
             ws = torch.empty(ops.attention_decode_workspace(B, Hq, hd, ns), dtype=torch.uint8, device=dev)
 
             def run():
@@ -30,10 +34,18 @@ def main():
                     ops.attention_decode(q, Kc[i], Vc[i], O, B, Hq, Hkv, hd, Smax, kvl, ns, ws)
             run()
             torch.cuda.synchronize()
+            if os.environ.get("GRAPH") == "1":      # replayed from a hipGraph, as the decode step runs them
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                g.replay()
+                launch = g.replay
+            else:
+                launch = run
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                run()
+                launch()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 / L * 1e3
