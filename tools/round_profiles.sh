@@ -3,7 +3,7 @@
 # SQ/GRBM counter passes of the GEMM and attention micro-benchmarks, a clock/power trace, and the default bench line.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-R=${R:-r3}
+R=${R:-r4}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof
 mkdir -p $O
 python bench.py --steps 3 --warmup 1 > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
@@ -15,7 +15,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-f
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT \
    -d $O/pmc_sq_gemm --output-format csv -- env REPS=2 SHAPES=9 python $GRAFT_REPO_ROOT/tools/bench_gemm.py > $O/pmc_sq_gemm.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE GRBM_COUNT \
-   -d $O/pmc_sq_attn --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_attn.py > $O/pmc_sq_attn.log 2>&1
+   -d $O/pmc_sq_attn --output-format csv -- env VROW=1 KV_PREFIX=1 python $GRAFT_REPO_ROOT/tools/bench_attn.py > $O/pmc_sq_attn.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/smi_trace.py $O/smi_bench.json -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/smi_bench.log 2>&1
 find $O/kt1b -name '*kernel_stats.csv' -exec cp {} $O/${R}_kernel_stats.csv \;
@@ -37,6 +37,8 @@ ls -la $O; cat $O/pmc_summary.log
 timeout 900 python bench.py --no-cpu-baseline --model gar_8b --max-num-tiles 8 --steps 2 > $O/bench_gar8b.log 2>&1
 timeout 900 python bench.py --no-cpu-baseline --workload multi_region --steps 2 > $O/bench_multi.log 2>&1
 timeout 900 python bench.py --no-cpu-baseline --workload video --steps 2 > $O/bench_video.log 2>&1
+timeout 600 python bench.py --no-cpu-baseline --batch 1 --steps 5 --warmup 2 > $O/bench_batch1.log 2>&1
+tail -1 $O/bench_batch1.log > $O/${R}_bench_batch1.json
 tail -1 $O/bench_default.log > $O/${R}_bench_default.json
 tail -1 $O/bench_gar8b.log > $O/${R}_bench_gar8b.json
 tail -1 $O/bench_multi.log > $O/${R}_bench_multi_region.json
