@@ -30,48 +30,6 @@ extern "C" int gar_check_device(int device) {
     return GAR_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// CU partitioning (round 4): a stream whose kernels run on a subset of the chip's compute units, and the number of CUs the
-// persistent tile GEMM sizes its grid for. GenerationPipeline gives the prompt phase (MFMA-bound: ViT + prefill) most of the
-// chip and the decode loop of the previous batch (HBM-bound: weight + KV streaming) a few CUs of every XCD, so that the two
-// phases of consecutive batches really run side by side — without a partition the persistent GEMM owns every CU and a
-// second stream only gets the seams (round 3: +0.7 %).
-static int g_cu_budget[GAR_MAX_DEVICES] = {};
-
-extern "C" int gar_stream_create_cu_mask(const uint32_t* mask, int words, void** stream) {
-    GAR_CHECK_ARG(mask && words > 0 && stream, "gar_stream_create_cu_mask: bad args");
-    hipStream_t s = nullptr;
-    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) {
-        gar_set_error("gar_stream_create_cu_mask: %s", hipGetErrorString(e));
-        return GAR_ERR_UNSUPPORTED;
-    }
-    *stream = (void*)s;
-    return GAR_OK;
-}
-
-extern "C" int gar_stream_destroy(void* stream) {
-    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
-        gar_set_error("gar_stream_destroy failed");
-        return GAR_ERR_LAUNCH;
-    }
-    return GAR_OK;
-}
-
-extern "C" int gar_set_cu_budget(int cus) {
-    const int d = gar_current_device();
-    GAR_CHECK_ARG(d >= 0 && d < GAR_MAX_DEVICES && cus >= 0, "gar_set_cu_budget: bad args");
-    g_cu_budget[d] = cus;
-    return GAR_OK;
-}
-
-int gar_cu_budget() {          // CUs a persistent grid may count on: the budget when one is set, else every CU of the device
-    const int d = gar_current_device();
-    const int n = gar_num_cus();
-    if (d >= 0 && d < GAR_MAX_DEVICES && g_cu_budget[d] > 0 && g_cu_budget[d] < n) return g_cu_budget[d];
-    return n;
-}
-
 __global__ void counter_add_kernel(int32_t* c, int n, int delta) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) c[i] += delta;

@@ -1093,8 +1093,7 @@ static void launch_pp(const gar_gemm_params& p, int pm, int pn, int num_cus, hip
                        gar_gather_args{});                                                                      // persistent
 }
 
-int gar_cu_budget();             // core.hip: gar_set_cu_budget, or every CU
-static int pp_num_cus() { return gar_cu_budget(); }
+static int pp_num_cus() { return gar_num_cus(); }
 
 // Patch-embed + mask-embed convolutions with the patches DMA'd from the image tiles into LDS (see the GATHER notes above).
 // x[t, token_offset + patch, :] = [pixel patch | mask patch] Wg^T + pos[token_offset + patch].  Returns GAR_ERR_UNSUPPORTED

@@ -42,9 +42,6 @@ SIGNATURES = {
     "gar_abi_version": ([], _i),
     "gar_last_error": ([], C.c_char_p),
     "gar_check_device": ([_i], _i),
-    "gar_stream_create_cu_mask": ([C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)], _i),
-    "gar_stream_destroy": ([_vp], _i),
-    "gar_set_cu_budget": ([_i], _i),
     "gar_gemm": ([_i, C.POINTER(GemmParams), _vp], _i),
     "gar_gemm_tile_takes": ([_i, C.POINTER(GemmParams)], _i),
     "gar_tokens_add": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),

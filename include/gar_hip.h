@@ -74,17 +74,6 @@ const char* gar_last_error(void);
 /* 0 if `device` is a gfx950 part, GAR_ERR_ARCH otherwise (the library holds gfx950 code objects only). */
 int gar_check_device(int device);
 
-/* CU partitioning (ABI v10). The reference runs one request at a time on one stream (Threading row of SURVEY.md section 8b); a
- * server that keeps two batches in flight gives the MFMA-bound prompt phase (ViT + prefill) most of the chip and the HBM-bound
- * decode loop of the previous batch a few CUs of every XCD, on two streams that really run side by side:
- *   gar_stream_create_cu_mask: hipStream_t (returned as void*) restricted to the CUs whose bit is set in mask[words] (bit i of
- *     word i / 32 = CU i in the runtime's numbering); GAR_ERR_UNSUPPORTED when the runtime refuses. gar_stream_destroy frees it.
- *   gar_set_cu_budget: the number of CUs the persistent tile GEMM (one workgroup per CU) sizes its grid for on the current
- *     device — the CU count of the masked stream it is launched on; 0 restores "every CU". */
-int gar_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
-int gar_stream_destroy(void* stream);
-int gar_set_cu_budget(int cus);
-
 typedef struct gar_gemm_params {
     const void* A;  int64_t lda;       /* [M, K]                                                   */
     const void* W;  int64_t ldw;       /* [N, K]  (nn.Linear weight)                               */
