@@ -75,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--decode-probe-steps", type=int, default=2,
                     help="eager decode steps timed kernel by kernel AFTER the timed region (rank 0) for the roofline_other entries of "
                          "the kernels that run inside the hipGraph during it (decode attention, decode GEMVs); 0 = off")
+    ap.add_argument("--vit-chunk-rows", type=int, default=0, help="A/B: cap on the token rows of one vision-tower pass (GARModel.VIT_CHUNK_ROWS)")
+    ap.add_argument("--prefill-chunk-rows", type=int, default=0, help="A/B: cap on the rows of one prefill pass (GARModel.PREFILL_CHUNK_ROWS)")
     ap.add_argument("--no-prune-last-layer", action="store_true",
                     help="A/B: the last Llama prefill layer over all S rows (the reference's computation) instead of its last row only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,6 +234,10 @@ class GpuRuntime:
             model.VIT_V_ROW_MAJOR = False
         if args.no_prune_last_layer:
             model.PRUNE_LAST_PREFILL_LAYER = False
+        if args.vit_chunk_rows:
+            model.VIT_CHUNK_ROWS = args.vit_chunk_rows
+        if args.prefill_chunk_rows:
+            model.PREFILL_CHUNK_ROWS = args.prefill_chunk_rows
         return model, W
 
     def build_batches(self, args, cfg, rank, world, device):
