@@ -406,8 +406,11 @@ static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
         // more 16-row weight tiles than CUs (a block's staging regions fill a CU's LDS: one block per CU): two tiles per
         // block keep the grid to one round and halve the activation re-reads — Llama-3.1-8B's qkv (N = 6144, 384 tiles)
         // 24.6 -> 18.2 us with cold weights; at N = 4096 (256 tiles) and below one tile per block stays faster
+        // (split-K slices count as blocks: `down` at N = 4096 x 2 slices, or N = 2048 x 4, also fills the chip with two-tile
+        // blocks — four row tiles re-read per ONE weight tile is 4 bytes of L2 traffic per weight byte, round 4)
+        const int nsp = (EPI == GAR_EPI_NONE && p.split_k > 1) ? p.split_k : 1;
         if (p.N >= wide && !p.norm_w) launch_skinny<EPI, 4, 4>(p, s);
-        else if (p.N > 16 * 256 && !p.norm_w) launch_skinny<EPI, 4, 2>(p, s);
+        else if ((p.N > 16 * 256 || (p.N / 32) * nsp >= 256) && !p.norm_w) launch_skinny<EPI, 4, 2>(p, s);
         else launch_skinny<EPI, 4, NT0>(p, s);
     }
 }

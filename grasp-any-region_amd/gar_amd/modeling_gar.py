@@ -533,8 +533,11 @@ class GARModel:
     _CAPACITY_FAMILIES = ("vit", "emb", "prefill")
     MAX_LLM_STATES = 2
     SPLITK_MAX_ROWS = 64      # csrc/gemm.hip: split_k > 1 and gar_splitk_residual_rmsnorm are built for M <= 64 rows
-    DOWN_SPLIT_K = 2          # K slices of the decode `down` GEMM at more than FUSE_NORM_MAX_BATCH rows (1 = off; 2 and 4
-                              # measure the same 21.6-21.9 us per layer against 28.6 unsplit, tools/bench_skinny.py)
+    DOWN_SPLIT_K = 0          # K slices of the decode `down` GEMM at more than FUSE_NORM_MAX_BATCH rows: 0 = as many as give the
+                              # two-weight-tile blocks of the skinny kernel a full grid — (hidden / 32) * slices >= 256: 4 at
+                              # hidden 2048, 2 at 4096 (round 4: four row tiles re-read per ONE weight tile was 4 bytes of L2
+                              # traffic per weight byte; GAR-1B 20.4 -> 18.7 us per layer with the reduce, GAR-8B 52.5 -> 44.1;
+                              # unsplit 27.3 / 50.1; tools/bench_skinny.py); 1 = off
 
     def _buf(self, key: tuple, name: str, shape, dtype=None, zero=False):
         dtype = dtype or self.dtype
@@ -1036,8 +1039,9 @@ class GARModel:
         # whose fp32 products are reduced — with the residual add and, on the last layer, the final RMSNorm — by the launch that
         # follows anyway (gar_gemm's split_k and gar_splitk_residual_rmsnorm take at most SPLITK_MAX_ROWS rows; larger batches
         # keep EPI_RES)
-        split = self.DOWN_SPLIT_K if (B > self.FUSE_NORM_MAX_BATCH and B <= self.SPLITK_MAX_ROWS and bf16
-                                      and F % (64 * self.DOWN_SPLIT_K) == 0 and C_l <= 4096) else 1
+        want = self.DOWN_SPLIT_K or (4 if C_l <= 2048 else 2)
+        split = want if (B > self.FUSE_NORM_MAX_BATCH and B <= self.SPLITK_MAX_ROWS and bf16
+                         and F % (64 * want) == 0 and C_l <= 4096) else 1
         partial = self._buf(key, "down_partial", (split, B, C_l), torch.float32) if split > 1 else None
         normed = None
         gu_folded = folded and (self.DECODE_GU_NORM_FOLDED or "gu" not in self.layers[0])

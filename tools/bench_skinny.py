@@ -61,13 +61,13 @@ def main():
             print(f"M={M:3d} {name:8s} N={N:6d} K={K:5d}  {us:8.1f} us  {nb / us / 1e6:7.2f} TB/s", flush=True)
         print(f"M={M:3d} GEMMs of one decode step (16 layers + head): {tot / 1e3:.3f} ms", flush=True)
         if M > 16:      # `down` as split-K partials + the fused reduce / residual / RMSNorm launch, against down(EPI_RES) + rmsnorm
-            N, K = 2048, 8192
+            N, K = (4096, 14336) if os.environ.get("MODEL") == "8b" else (2048, 8192)
             ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(L)]
             a = torch.randn(M, K, device=dev).to(torch.bfloat16)
             h = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
             y = torch.empty_like(h)
             g = torch.ones(N, device=dev, dtype=torch.bfloat16)
-            for S in (1, 2, 4, 8):
+            for S in ((1, 2, 4) if N > 2048 else (1, 2, 4, 8)):
                 part = torch.empty(S, M, N, device=dev, dtype=torch.float32)
 
                 def run(what):
