@@ -6,6 +6,9 @@
 //   * deferred rescale: O / l are rescaled only when some row's running max grew by more than 2^RESCALE_THR.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -73,6 +76,12 @@ typedef short tr4_t __attribute__((ext_vector_type(4)));
 #endif
 #ifndef ATTN_PK_SUM        /* n > 0: row sums of P in n packed-fp32 partial chains (v_pk_add_f32) instead of 32 scalar adds per tile */
 #define ATTN_PK_SUM 0
+#endif
+#ifndef ATTN_PIPE          /* 1: head_dim 64, row-major V goes to the in-wave pipelined kernel (v3, below) */
+#define ATTN_PIPE 0
+#endif
+#ifndef ATTN_PIPE_PFD      /* v3: LDS fragment reads run this many MFMAs ahead */
+#define ATTN_PIPE_PFD 3
 #endif
 #ifndef ATTN_MFMA_ROWSUM   /* 1: row sums of P on the matrix pipe (ones x P), instead of 32 VALU adds per tile and lane */
 #define ATTN_MFMA_ROWSUM 0
@@ -524,6 +533,456 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     }
 }
 
+#ifdef ATTN_PIPE_TIMELINE   /* diagnostic build: stamps between the segments of a v3 iteration (tools/attn_timeline.py, PIPE=1) */
+#define TLP(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TLP(i)
+#endif
+// LDS fragment reads as inline asm with hand-counted waits. Two reasons: (1) the compiler puts `s_waitcnt vmcnt(0)` in
+// front of every ds_read_b64_tr_b16 that follows an LDS-DMA (the builtin carries no memory operand, so the read "may
+// alias" the tile in flight) — the next tile's DMA is then waited for in the middle of the current tile; (2) in the
+// pipelined loop the waits must let the reads of the NEXT MFMAs stay in flight (LDS returns in order: lgkmcnt(n) with n =
+// the reads issued after the wanted one). The wait is tied to the fragment ("+v") so that the MFMA cannot move above it.
+#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+#define DS_READ_TR64(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
+template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: the same arithmetic as v2 (bit-identical results), software-pipelined INSIDE the wave. tools/interleave_probe.hip: a
+// wave's own VALU instructions issue in the 32-cycle shadow of its own MFMAs almost for free (16 x (MFMA + 4 fma) runs at
+// the bare MFMA rate, 16 x (MFMA + 2 exp + 2 add + cvt + 1) at 0.77 of it), while across the waves of a SIMD the oldest
+// wave's stalled MFMA holds the issue port (tools/coissue_probe.hip: MFMA time + VALU time). v2's loop is QK^T(j) ->
+// softmax(j) -> PV(j), each a dependent of the one before, so its softmax never sits beside its own MFMAs. Here iteration
+// j runs three INDEPENDENT pieces — the MFMAs of QK^T(j + 1) and PV(j - 1), and the exp / row-sum / pack of tile j —
+// as sixteen bundles of [one MFMA | 2 v_exp, 2 v_add, 1 v_cvt_pk, the LDS fragment reads of the MFMA after next], fenced
+// by sched_barrier so that the binary keeps that order. Row-major V and head_dim 64 only (the ViT's and Llama-3.2-1B's).
+// Tiles that need the exact path (the first, masked ones, a failed lazy check) and the ends of the pipeline run the three
+// pieces one after the other, in v2's order of operations on every accumulator: results are bit-identical to v2's.
+// LDS: rings of four K and four V tiles, the DMA two tiles ahead of its reader (an iteration is shorter than a DMA's
+// latency: the wait at its end is for the stage issued one iteration earlier); one workgroup barrier per tile, as in v2.
+// ~220 VGPRs: two waves per SIMD, two workgroups per CU.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bf16_v3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                              int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
+                                                              int kv_stride, const int32_t* __restrict__ kv_len_dev,
+                                                              const int32_t* __restrict__ kv_start, int kv_prefix) {
+    static_assert(HD == 64, "pipelined attention: head_dim 64");
+#ifdef ATTN_PIPE_TIMELINE
+    const unsigned tl_entry = (unsigned)__builtin_amdgcn_s_memtime();
+    unsigned tl_p[5] = {0u, 0u, 0u, 0u, 0u};
+#endif
+    constexpr int KRS = 128, KT = 64 * KRS, NKD = HD / 16, NDB = HD / 32, KI = KT / 4096;
+    constexpr int RING = 4;                     // tiles t live in slot t & 3 of each ring: the DMA runs two tiles ahead of its reader
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [RING][KT] | V ring [RING][KT]
+    const int PFX = !CAUSAL ? kv_prefix : 0;
+    const int kv_len = (kv_len_dev ? kv_len_dev[0] : kv_len_arg) - PFX;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nqb = (q_len + 127) >> 7;
+    int wk;                                      // XCD-aware work list, as in v2
+    {
+        const int total = gridDim.x, L = blockIdx.x;
+        const int per = total >> 3, rem = total & 7, xcd = L & 7, slot = L >> 3;
+        wk = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    }
+    const int qb = nqb - 1 - (wk % nqb);
+    const int head = (wk / nqb) % Hq, b = wk / (nqb * Hq);
+    const int kvh = head / (Hq / Hkv);
+    const int q0 = qb * 128 + wave * 32;
+    const int coff = kv_len - q_len;
+    const bf16_t* Qp = Q + (((int64_t)b * Hq + head) * q_pad) * HD;
+    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
+    const unsigned slab = (unsigned)kv_stride * HD * 2u;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
+    int voffK, voffV;
+    {
+        const int row = wave * 8 + (lane >> 3);                    // DMA piece = 8 rows x 128 B, lane-linear LDS image
+        voffK = row * 128 + (((lane & 7) ^ key_of<128>(row)) << 4);
+        voffV = row * 128 + (((lane & 7) ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    // tiles past the last one are staged too, from past the end of the slab (zero fill, no memory traffic): every stage is
+    // 2 KI DMA instructions, which is what the counted vmcnt waits below rely on
+    auto stage_k = [&](int t, bool live) {
+        char* ks = smem + (t & (RING - 1)) * KT;
+        const unsigned base = live ? ((unsigned)t * 64u + (unsigned)PFX) * 128u : slab;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
+                                                     voffK + (int)(base + (unsigned)i * 4096u), 0, 0, 0);
+    };
+    auto stage_v = [&](int t, bool live) {
+        char* vs = smem + RING * KT + (t & (RING - 1)) * KT;
+        const unsigned base = live ? ((unsigned)t * 64u + (unsigned)PFX) * 128u : slab;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
+                                                     voffV + (int)(base + (unsigned)i * 4096u), 0, 0, 0);
+    };
+
+    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
+    const int t_lo = kv_lo >> 6;
+    int kv_end = kv_len;
+    if (CAUSAL) kv_end = min(kv_len, max(qb * 128 + 127 + coff, kv_lo) + 1);
+    const int ntiles = (kv_end + 63) / 64;
+    // The first tiles' DMA goes out before anything else of the prologue: a workgroup lives for ~16 (ViT) tiles and only two
+    // are resident per CU, so a prologue of three dependent memory round trips (Q and the folded key -> stage -> wait) is
+    // not hidden by neighbours as it is in v2 (measured: 8000 of a workgroup's 39000 cycles).
+    if (ntiles > t_lo) {
+        stage_k(t_lo, true);
+        stage_k(t_lo + 1, t_lo + 1 < ntiles);
+        stage_k(t_lo + 2, t_lo + 2 < ntiles);    // these two are "the stage of iteration t_lo - 1"
+        stage_v(t_lo, true);
+#ifdef ATTN_PIPE_TIMELINE
+        tl_p[0] = (unsigned)__builtin_amdgcn_s_memtime() - tl_entry;
+#endif
+    }
+    bf16x8 qf[NKD];
+    {
+        const int qrow = min(q0 + l31, q_pad - 1);
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+            qf[kd] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * HD + kd * 16 + h * 8);
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 negm = zero16_c();
+#ifdef ATTN_PIPE_TIMELINE
+    tl_p[1] = (unsigned)__builtin_amdgcn_s_memtime() - tl_entry;
+#endif
+    if (PFX) {                                   // key / value row 0 folded into the initial softmax state (see v2)
+        float part = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + kd * 16 + h * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                part = __builtin_fmaf(bf2f((bf16_t)qf[kd][e]), bf2f((bf16_t)kf[e]), part);
+        }
+        m_run = part + __shfl_xor(part, 32, 64);
+        l_run = h == 0 ? 1.0f : 0.f;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v4[4];
+                ld4(Vp + d * 32 + g * 8 + h * 4, v4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[d][g * 4 + r] = v4[r];
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+    }
+
+    const bool wave_active = q0 < q_len;
+    // tiles this wave takes no part in (wave-uniform, monotone in t): it still stages its DMA pieces and meets the barriers
+    auto skip = [&](int t) { return !wave_active || (CAUSAL && t * 64 > max(q0 + 31 + coff, kv_lo)); };
+
+#ifdef ATTN_PIPE_TIMELINE
+    tl_p[2] = (unsigned)__builtin_amdgcn_s_memtime() - tl_entry;
+#endif
+    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2<->3 swapped
+    int koff[2], kkey[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int row = blk * 32 + prow;
+        koff[blk] = row * KRS;
+        kkey[blk] = key_of<KRS>(row);
+    }
+    int vtr;
+    {
+        const int i = lane & 15, r = 8 * h + (i >> 2);
+        const int col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+        const int key4 = ((r >> 1) & 1) << 2;
+        vtr = r * KRS + ((((col >> 3) ^ key4) << 4) | ((col & 7) << 1));
+    }
+    // MFMA q of a tile's QK^T (two chains in turn): block q & 1, k-step q >> 1;  MFMA v of its PV: d-block v & 1, kv step v >> 1
+    // LDS byte addresses of this lane's fragment of MFMA q / of d-block d. Ring slot of a tile = t & 3: bit 0 is a
+    // compile-time offset in the loop bodies (tile parity), bit 1 (2 KT bytes) lives in these registers and is flipped by
+    // body<1> every second tile — ten v_xor per two tiles instead of four copies of the loop body.
+    unsigned kaddr[8], vaddr[2];
+    const unsigned kbit1 = (unsigned)((t_lo >> 1) & 1), vbit1 = (unsigned)((((t_lo - 1) >> 1) & 1) ^ (t_lo & 1));
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        kaddr[q] = (unsigned)(uintptr_t)LDS_AS(smem) + (unsigned)(koff[q & 1] + ((((q >> 1) * 2 + h) ^ kkey[q & 1]) << 4)) + kbit1 * (2u * KT);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+        vaddr[d] = (unsigned)(uintptr_t)LDS_AS(smem) + (unsigned)(RING * KT + (vtr ^ (d << 6))) + vbit1 * (2u * KT);
+    auto kfrag = [&](const char* ks, int q) {
+        const int blk = q & 1, kd = q >> 1;
+        return *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
+    };
+    // asm reads (no wait): K fragment of MFMA q_ / V fragment of MFMA v_ from ring slot (bit 1 in the address registers, bit 0 = SLOT)
+    auto kread = [&](auto SLOT, auto QI, bf16x8& f) {
+        constexpr int slot = decltype(SLOT)::value, q_ = decltype(QI)::value;
+        const unsigned a = kaddr[q_];            // (a local: asm operands do not capture in a generic lambda)
+        DS_READ_B128(f, a, slot * KT);
+    };
+    auto vread = [&](auto SLOT, auto VI, bf16x8& f) {
+        constexpr int slot = decltype(SLOT)::value, v_ = decltype(VI)::value, d = v_ & 1, st = v_ >> 1;
+        tr4_t lo, hi;
+        const unsigned a = vaddr[d];
+        DS_READ_TR64(lo, a, slot * KT + (st * 16) * KRS);
+        DS_READ_TR64(hi, a, slot * KT + (st * 16 + 4) * KRS);
+        f = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    f32x16 s[2][2];                 // [tile parity][kv block]: scores of tile j in s[j & 1]
+    unsigned pw[2][4][4];           // [tile parity][kv step][word]: bf16 P of tile j, the PV B operands
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pw[a][c][w] = 0u;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) s[a][c] = zero16_c();
+    auto pfrag = [&](const unsigned (&p)[4][4], int st) {
+        const u32x4 w = {p[st][0], p[st][1], p[st][2], p[st][3]};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    auto qk_tile = [&](const char* ks, f32x16 (&so)[2]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            so[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(ks, q), qf[q >> 1], (q >> 1) == 0 ? negm : so[q & 1], 0, 0, 0);
+    };
+    auto pv_tile = [&](auto SLOT, const unsigned (&p)[4][4]) {
+        static_for<8>([&](auto VI) {
+            constexpr int v = decltype(VI)::value;
+            bf16x8 vf;
+            vread(SLOT, VI, vf);
+            lgkm_wait<0>(vf);
+            o[v & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfrag(p, v >> 1), o[v & 1], 0, 0, 0);
+        });
+    };
+    // p = exp2(s) (the scores carry -m), row sum in v2's order, bf16 pack
+    auto exp_pack = [&](const f32x16 (&si)[2], unsigned (&p)[4][4]) {
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int blk = i >> 3, r = (i & 7) * 2;
+            const float ea = __builtin_amdgcn_exp2f(si[blk][r]), eb = __builtin_amdgcn_exp2f(si[blk][r + 1]);
+            ps += ea;
+            ps += eb;
+            p[i >> 2][i & 3] = cvt_pk(ea, eb);
+        }
+        return ps;
+    };
+#ifdef ATTN_PIPE_TIMELINE
+    unsigned tl_t[6], tl_sum[5] = {0u, 0u, 0u, 0u, 0u}, tl_n = 0u, tl_loop0 = 0u, tl_loop1 = 0u;
+    const unsigned tl_begin = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+    // one iteration of the pipeline, P = j & 1:  QK^T(j + 1) -> s[P ^ 1],  softmax(j): s[P] -> pw[P],  PV(j - 1): pw[P ^ 1] -> o
+    auto body = [&](auto PC, const int j) {
+        constexpr int P = decltype(PC)::value;                   // j & 1: the s / pw pair, and bit 0 of the ring slots
+        TLP(0)
+        constexpr int KS = P ^ 1, VS = P ^ 1;                    // bit 0 of the slots of K(j + 1), V(j - 1)
+        if constexpr (P == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) kaddr[q] ^= 2u * KT;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) vaddr[d] ^= 2u * KT;
+        }
+        const char* ks_n = smem + ((j + 1) & (RING - 1)) * KT;
+        stage_k(j + 3, j + 3 < ntiles);
+        stage_v(j + 1, j + 1 < ntiles);
+        TLP(1)
+        const int kv0 = j * 64;
+        const bool do_qk = j + 1 < ntiles && !skip(j + 1), do_sm = !skip(j), do_pv = j > t_lo && !skip(j - 1);
+        const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);
+        bool exact = j == t_lo || need_mask;
+        const bool fast = do_qk && do_sm && do_pv && !exact;
+        float ps = 0.f;
+        bool redo = false;
+        if (fast) {
+            // fragment of MFMA m (even: QK^T q = m / 2, odd: PV v = m / 2) is read PFD bundles ahead of it
+            constexpr int PFD = ATTN_PIPE_PFD;
+            bf16x8 fr[16];
+            auto fread = [&](auto MI) {
+                constexpr int m = decltype(MI)::value;
+                if constexpr (m & 1) vread(std::integral_constant<int, VS>{}, std::integral_constant<int, (m >> 1)>{}, fr[m]);
+                else kread(std::integral_constant<int, KS>{}, std::integral_constant<int, (m >> 1)>{}, fr[m]);
+            };
+            static_for<PFD>([&](auto MI) { fread(MI); });
+            float ea = 0.f, eb = 0.f;
+            static_for<16>([&](auto II) {
+                constexpr int i = decltype(II)::value;
+                // LDS reads issued after this MFMA's fragment: those of MFMAs i + 1 .. i + PFD - 1 (1 for a K fragment, 2 for a V one)
+                constexpr int hi_m = (i + PFD - 1 < 15) ? i + PFD - 1 : 15;
+                constexpr int newer = (hi_m - i) + ((hi_m + 1) / 2 - (i + 1) / 2);
+                __builtin_amdgcn_sched_barrier(0);
+                lgkm_wait<newer>(fr[i]);
+                if constexpr (i & 1) {
+                    constexpr int v = i >> 1;
+                    o[v & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pfrag(pw[P ^ 1], v >> 1), o[v & 1], 0, 0, 0);
+                } else {
+                    constexpr int q = i >> 1;
+                    s[P ^ 1][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[q >> 1], (q >> 1) == 0 ? negm : s[P ^ 1][q & 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int blk = i >> 3, r = (i & 7) * 2;
+                const float na = __builtin_amdgcn_exp2f(s[P][blk][r]), nb = __builtin_amdgcn_exp2f(s[P][blk][r + 1]);
+                if constexpr (i > 0) {
+                    ps += ea;
+                    ps += eb;
+                    pw[P][(i - 1) >> 2][(i - 1) & 3] = cvt_pk(ea, eb);
+                }
+                ea = na;
+                eb = nb;
+                if constexpr (i + PFD < 16) fread(std::integral_constant<int, i + PFD>{});
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            ps += ea;
+            ps += eb;
+            pw[P][3][3] = cvt_pk(ea, eb);
+            redo = !__all(ps < 65536.0f);
+        } else if (do_pv) {
+            pv_tile(std::integral_constant<int, VS>{}, pw[P ^ 1]);
+        }
+        TLP(2)
+        if (do_sm && (!fast || redo)) {
+            if (!fast && !exact) {
+                ps = exp_pack(s[P], pw[P]);
+                exact = !__all(ps < 65536.0f);
+            }
+            if (exact || redo) {
+                if (need_mask) {
+                    const int qi = q0 + l31;
+                    const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kv = kv0 + blk * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
+                            s[P][blk][r] = (kv <= lim && kv >= kv_lo) ? s[P][blk][r] : -INFINITY;
+                        }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[P][blk][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (!__all(mx + (-negm[0] - m_run) <= RESCALE_THR)) {
+                    const float m_base = -negm[0];
+                    const float m_new = fmaxf(m_run, mx + m_base);
+                    const float m_nu = m_new == -INFINITY ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);
+                    const float shift = m_base - m_nu;
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[P][blk][r] += shift;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[r] = -m_nu;
+                }
+                ps = exp_pack(s[P], pw[P]);
+            }
+        }
+        if (do_sm) l_run += ps;
+        // QK^T(j + 1) against the max that stands AFTER tile j (v2's order): not yet formed, or formed under the old one
+        if (do_qk && (!fast || redo)) qk_tile(ks_n, s[P ^ 1]);
+        // the stage of the PREVIOUS iteration (K(j + 2), V(j): what iteration j + 1 reads) has landed; this one's stays in flight
+        TLP(3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * KI) : "memory");
+        TLP(4)
+        __syncthreads();
+        TLP(5)
+#ifdef ATTN_PIPE_TIMELINE
+        if (fast && !redo) {
+            for (int i = 0; i < 5; ++i) tl_sum[i] += tl_t[i + 1] - tl_t[i];
+            ++tl_n;
+        }
+#endif
+    };
+
+    if (ntiles > t_lo) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (Q and the folded key's loads are younger than the DMA: a counted wait would count them)
+#ifdef ATTN_PIPE_TIMELINE
+        tl_p[3] = (unsigned)__builtin_amdgcn_s_memtime() - tl_entry;
+#endif
+        __syncthreads();
+#ifdef ATTN_PIPE_TIMELINE
+        tl_p[4] = (unsigned)__builtin_amdgcn_s_memtime() - tl_entry;
+#endif
+        if (!skip(t_lo)) {
+            if (t_lo & 1) qk_tile(smem + (t_lo & (RING - 1)) * KT, s[1]);
+            else qk_tile(smem + (t_lo & (RING - 1)) * KT, s[0]);
+        }
+        // (slot t_lo & 3 of the K ring is next written by iteration t_lo + 1, behind iteration t_lo's barrier)
+#ifdef ATTN_PIPE_TIMELINE
+        tl_loop0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+        int j = t_lo;
+        if (j & 1) {
+            body(std::integral_constant<int, 1>{}, j);
+            ++j;
+        }
+        for (; j + 1 < ntiles; j += 2) {
+            body(std::integral_constant<int, 0>{}, j);
+            body(std::integral_constant<int, 1>{}, j + 1);
+        }
+        if (j < ntiles) body(std::integral_constant<int, 0>{}, j);
+#ifdef ATTN_PIPE_TIMELINE
+        tl_loop1 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+        if (!skip(ntiles - 1)) {                 // drain: PV of the last tile, V(ntiles - 1) in slot (ntiles - 1) & 3
+            const unsigned want = (unsigned)(((ntiles - 1) >> 1) & 1);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                vaddr[d] = (unsigned)(uintptr_t)LDS_AS(smem) + (unsigned)(RING * KT + (vtr ^ (d << 6))) + want * (2u * KT);
+            if ((ntiles - 1) & 1) pv_tile(std::integral_constant<int, 1>{}, pw[1]);
+            else pv_tile(std::integral_constant<int, 0>{}, pw[0]);
+        }
+    }
+#ifdef ATTN_PIPE_TIMELINE
+    {
+        const unsigned tl_total = (unsigned)__builtin_amdgcn_s_memtime() - tl_begin;
+        const bool writer = b == 0 && head == 0 && qb == nqb / 2;
+        if (writer && lane < 16) {
+            unsigned v = 0u;
+            for (int i = 0; i < 5; ++i) v = lane == i ? tl_sum[i] : v;
+            v = lane == 7 ? tl_n : lane == 8 ? tl_total : lane == 9 ? (unsigned)ntiles : v;
+            v = lane == 13 ? tl_p[0] : lane == 14 ? tl_p[1] : lane == 15 ? tl_p[2] : lane == 5 ? tl_p[3] : lane == 6 ? tl_p[4] : v;
+            v = lane == 10 ? tl_loop0 - tl_entry : lane == 11 ? tl_loop1 - tl_loop0 : lane == 12 ? (unsigned)__builtin_amdgcn_s_memtime() - tl_loop1 : v;
+            reinterpret_cast<unsigned*>(O + (int64_t)wave * ((int64_t)Hq * HD))[lane] = v;
+        }
+        if (b == 0 && head == 0 && qb == 0) return;
+    }
+#endif
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const int qi = q0 + l31;
+    if (qi < q_len) {
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        bf16_t* op = O + ((int64_t)b * q_len + qi) * ((int64_t)Hq * HD) + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv, o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv};
+                st4(op + d * 32 + g * 8 + h * 4, v);
+            }
+    }
+}
+
 // returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip).
 // vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
@@ -536,7 +995,15 @@ bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O,
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
                        (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix)
-    if (hd == 64) {
+    if (hd == 64 && vrow && ATTN_PIPE) {
+        const int lds3 = 8 * kt;
+        if (causal)
+            hipLaunchKernelGGL((attn_bf16_v3_kernel<64, true>), grid, block, lds3, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
+                               (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix);
+        else
+            hipLaunchKernelGGL((attn_bf16_v3_kernel<64, false>), grid, block, lds3, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
+                               (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix);
+    } else if (hd == 64) {
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }
     }
