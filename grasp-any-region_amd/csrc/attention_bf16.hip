@@ -80,6 +80,9 @@ typedef short tr4_t __attribute__((ext_vector_type(4)));
 #ifndef ATTN_PIPE          /* 1: head_dim 64, row-major V goes to the in-wave pipelined kernel (v3, below) */
 #define ATTN_PIPE 0
 #endif
+#ifndef ATTN_V2_ASM_TR     /* 1: v2's transposing V reads as inline asm (no compiler-inserted vmcnt(0) in front of them) */
+#define ATTN_V2_ASM_TR 0
+#endif
 #ifndef ATTN_PIPE_DIAG     /* timing experiments with WRONG results: 1 no DMA in the loop, 2 no barrier, 4 exponentials only, 8 PFD fragment reads only */
 #define ATTN_PIPE_DIAG 0
 #endif
@@ -89,6 +92,24 @@ typedef short tr4_t __attribute__((ext_vector_type(4)));
 #ifndef ATTN_MFMA_ROWSUM   /* 1: row sums of P on the matrix pipe (ones x P), instead of 32 VALU adds per tile and lane */
 #define ATTN_MFMA_ROWSUM 0
 #endif
+#ifdef ATTN_PIPE_TIMELINE   /* diagnostic build: stamps between the segments of a v3 iteration (tools/attn_timeline.py, PIPE=1) */
+#define TLP(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TLP(i)
+#endif
+// LDS fragment reads as inline asm with hand-counted waits. Two reasons: (1) the compiler puts `s_waitcnt vmcnt(0)` in
+// front of every ds_read_b64_tr_b16 that follows an LDS-DMA (the builtin carries no memory operand, so the read "may
+// alias" the tile in flight) — the next tile's DMA is then waited for in the middle of the current tile; (2) in the
+// pipelined loop the waits must let the reads of the NEXT MFMAs stay in flight (LDS returns in order: lgkmcnt(n) with n =
+// the reads issued after the wanted one). The wait is tied to the fragment ("+v") so that the MFMA cannot move above it.
+#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+#define DS_READ_TR64(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
+template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
@@ -478,7 +499,17 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                             vf = vfa[d][blk][tt];
                         } else
 #endif
-                        if (VROW) {
+                        if (VROW && ATTN_V2_ASM_TR) {
+                            // (asm: the builtin's read is put behind s_waitcnt vmcnt(0) — the NEXT tile's DMA — by the compiler)
+                            const unsigned va = (unsigned)(uintptr_t)LDS_AS(vs) + (unsigned)(vtr ^ (d << 6));
+                            tr4_t lo, hi;
+                            if (blk == 0 && tt == 0) { DS_READ_TR64(lo, va, 0); DS_READ_TR64(hi, va, 4 * KRS); }
+                            if (blk == 0 && tt == 1) { DS_READ_TR64(lo, va, 16 * KRS); DS_READ_TR64(hi, va, 20 * KRS); }
+                            if (blk == 1 && tt == 0) { DS_READ_TR64(lo, va, 32 * KRS); DS_READ_TR64(hi, va, 36 * KRS); }
+                            if (blk == 1 && tt == 1) { DS_READ_TR64(lo, va, 48 * KRS); DS_READ_TR64(hi, va, 52 * KRS); }
+                            vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            lgkm_wait<0>(vf);
+                        } else if (VROW) {
                             // this lane's chunk of its group's [4 kv][16 d] block: kv row (blk*32 + tt*16 + 8h) + (i >> 2) (+4),
                             // d columns d*32 + 16 ((lane >> 4) & 1) + 4 (i & 3);  i = lane & 15.  vtr = byte offset of (kv row i >> 2 of
                             // the wave-tile's row 8h, that d chunk) with the row key of rows 0-1; rows 2-3 flip chunk bit 2
@@ -535,24 +566,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             }
     }
 }
-
-#ifdef ATTN_PIPE_TIMELINE   /* diagnostic build: stamps between the segments of a v3 iteration (tools/attn_timeline.py, PIPE=1) */
-#define TLP(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TLP(i)
-#endif
-// LDS fragment reads as inline asm with hand-counted waits. Two reasons: (1) the compiler puts `s_waitcnt vmcnt(0)` in
-// front of every ds_read_b64_tr_b16 that follows an LDS-DMA (the builtin carries no memory operand, so the read "may
-// alias" the tile in flight) — the next tile's DMA is then waited for in the middle of the current tile; (2) in the
-// pipelined loop the waits must let the reads of the NEXT MFMAs stay in flight (LDS returns in order: lgkmcnt(n) with n =
-// the reads issued after the wanted one). The wait is tied to the fragment ("+v") so that the MFMA cannot move above it.
-#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
-#define DS_READ_TR64(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
-template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
-template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v3: the softmax of one 32-key block in the shadow of the MFMAs of its neighbours, inside ONE wave.
