@@ -6,9 +6,6 @@
 //   * deferred rescale: O / l are rescaled only when some row's running max grew by more than 2^RESCALE_THR.
 #include <stdlib.h>
 
-#include <type_traits>
-#include <utility>
-
 #include "common.h"
 
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -77,39 +74,9 @@ typedef short tr4_t __attribute__((ext_vector_type(4)));
 #ifndef ATTN_PK_SUM        /* n > 0: row sums of P in n packed-fp32 partial chains (v_pk_add_f32) instead of 32 scalar adds per tile */
 #define ATTN_PK_SUM 0
 #endif
-#ifndef ATTN_PIPE          /* 1: head_dim 64, row-major V goes to the in-wave pipelined kernel (v3, below) */
-#define ATTN_PIPE 0
-#endif
-#ifndef ATTN_V2_ASM_TR     /* 1: v2's transposing V reads as inline asm (no compiler-inserted vmcnt(0) in front of them) */
-#define ATTN_V2_ASM_TR 0
-#endif
-#ifndef ATTN_PIPE_DIAG     /* timing experiments with WRONG results: 1 no DMA in the loop, 2 no barrier, 4 exponentials only, 8 PFD fragment reads only */
-#define ATTN_PIPE_DIAG 0
-#endif
-#ifndef ATTN_PIPE_PFD      /* v3: LDS fragment reads run this many MFMAs ahead */
-#define ATTN_PIPE_PFD 3
-#endif
 #ifndef ATTN_MFMA_ROWSUM   /* 1: row sums of P on the matrix pipe (ones x P), instead of 32 VALU adds per tile and lane */
 #define ATTN_MFMA_ROWSUM 0
 #endif
-#ifdef ATTN_PIPE_TIMELINE   /* diagnostic build: stamps between the segments of a v3 iteration (tools/attn_timeline.py, PIPE=1) */
-#define TLP(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TLP(i)
-#endif
-// LDS fragment reads as inline asm with hand-counted waits. Two reasons: (1) the compiler puts `s_waitcnt vmcnt(0)` in
-// front of every ds_read_b64_tr_b16 that follows an LDS-DMA (the builtin carries no memory operand, so the read "may
-// alias" the tile in flight) — the next tile's DMA is then waited for in the middle of the current tile; (2) in the
-// pipelined loop the waits must let the reads of the NEXT MFMAs stay in flight (LDS returns in order: lgkmcnt(n) with n =
-// the reads issued after the wanted one). The wait is tied to the fragment ("+v") so that the MFMA cannot move above it.
-#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
-#define DS_READ_TR64(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
-template <int N> __device__ __forceinline__ void lgkm_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "i"(N)); }
-template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-
 template <int HD, bool CAUSAL, bool VROW = false>
 __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
@@ -499,17 +466,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                             vf = vfa[d][blk][tt];
                         } else
 #endif
-                        if (VROW && ATTN_V2_ASM_TR) {
-                            // (asm: the builtin's read is put behind s_waitcnt vmcnt(0) — the NEXT tile's DMA — by the compiler)
-                            const unsigned va = (unsigned)(uintptr_t)LDS_AS(vs) + (unsigned)(vtr ^ (d << 6));
-                            tr4_t lo, hi;
-                            if (blk == 0 && tt == 0) { DS_READ_TR64(lo, va, 0); DS_READ_TR64(hi, va, 4 * KRS); }
-                            if (blk == 0 && tt == 1) { DS_READ_TR64(lo, va, 16 * KRS); DS_READ_TR64(hi, va, 20 * KRS); }
-                            if (blk == 1 && tt == 0) { DS_READ_TR64(lo, va, 32 * KRS); DS_READ_TR64(hi, va, 36 * KRS); }
-                            if (blk == 1 && tt == 1) { DS_READ_TR64(lo, va, 48 * KRS); DS_READ_TR64(hi, va, 52 * KRS); }
-                            vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            lgkm_wait<0>(vf);
-                        } else if (VROW) {
+                        if (VROW) {
                             // this lane's chunk of its group's [4 kv][16 d] block: kv row (blk*32 + tt*16 + 8h) + (i >> 2) (+4),
                             // d columns d*32 + 16 ((lane >> 4) & 1) + 4 (i & 3);  i = lane & 15.  vtr = byte offset of (kv row i >> 2 of
                             // the wave-tile's row 8h, that d chunk) with the row key of rows 0-1; rows 2-3 flip chunk bit 2
@@ -567,406 +524,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// v3: the softmax of one 32-key block in the shadow of the MFMAs of its neighbours, inside ONE wave.
-// tools/interleave_probe.hip: a wave's own VALU instructions issue under its own MFMAs almost for free (16 x (MFMA + 4 fma)
-// runs at the bare MFMA rate, 16 x (MFMA + 2 exp + 2 add + cvt + 1) at 0.77 of it), while across the waves of a SIMD the
-// oldest wave's stalled MFMA holds the issue port (tools/coissue_probe.hip: MFMA time + VALU time — v2's regime, whose
-// QK^T -> softmax -> PV of a tile are dependents of each other). Here the online softmax advances in blocks of 32 keys
-// (A = rows 0-31, B = rows 32-63 of a 64-key tile; the DMA, the LDS rings and the workgroup barrier stay per tile), and a
-// "half" runs three INDEPENDENT pieces:  the 4 MFMAs of QK^T of the NEXT block, the 4 MFMAs of PV of the PREVIOUS block,
-// and exp / row sum / bf16 pack of THIS block — as eight bundles [one MFMA | 2 v_exp, 2 v_add, 1 v_cvt_pk, the LDS
-// fragment reads of the MFMA three ahead], fenced by sched_barrier so that the binary keeps that order:
-//     half 1 of tile j:  QK^T(B_j) | PV(B_j-1) | softmax(A_j)         sync S_j: counted vmcnt, barrier, stage
-//     half 2 of tile j:  QK^T(A_j+1) | PV(A_j) | softmax(B_j)
-// Registers: one 16-register score block per parity and 8 of packed P — ~150 VGPRs, three waves per SIMD as in v2.
-// A tile is read from the sync of the tile before it to its own sync (K(t): S_t-1 .. S_t, V(t): S_t .. S_t+1), so rings of
-// THREE tiles keep the DMA TWO tiles ahead of its reader: S_j waits for the stage of S_j-2 only (vmcnt(4)) and then stages
-// K(j + 3) over K(j) and V(j + 2) over V(j - 1), both dead since half 1. 48 KiB of LDS, three workgroups per CU.
-// Blocks that need the exact path (the first tile, masked tiles, a failed lazy check) and the ends of the pipeline run the
-// three pieces one after the other. Row-major V and head_dim 64 only (the ViT's and Llama-3.2-1B's attention).
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 3) void attn_bf16_v3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                              const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                              int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
-                                                              int kv_stride, const int32_t* __restrict__ kv_len_dev,
-                                                              const int32_t* __restrict__ kv_start, int kv_prefix) {
-    static_assert(HD == 64, "pipelined attention: head_dim 64");
-#ifdef ATTN_PIPE_TIMELINE
-    const unsigned tl_entry = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
-    constexpr int KRS = 128, KT = 64 * KRS, NKD = HD / 16, NDB = HD / 32, KI = KT / 4096, RING = 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [RING][KT] | V ring [RING][KT]; tile t in slot t % 3
-    const int PFX = !CAUSAL ? kv_prefix : 0;
-    const int kv_len = (kv_len_dev ? kv_len_dev[0] : kv_len_arg) - PFX;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nqb = (q_len + 127) >> 7;
-    int wk;                                      // XCD-aware work list, as in v2
-    {
-        const int total = gridDim.x, L = blockIdx.x;
-        const int per = total >> 3, rem = total & 7, xcd = L & 7, slot = L >> 3;
-        wk = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
-    }
-    const int qb = nqb - 1 - (wk % nqb);
-    const int head = (wk / nqb) % Hq, b = wk / (nqb * Hq);
-    const int kvh = head / (Hq / Hkv);
-    const int q0 = qb * 128 + wave * 32;
-    const int coff = kv_len - q_len;
-    const bf16_t* Qp = Q + (((int64_t)b * Hq + head) * q_pad) * HD;
-    const bf16_t* Kp = K + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const bf16_t* Vp = V + (((int64_t)b * Hkv + kvh) * (int64_t)kv_stride) * HD;
-    const unsigned slab = (unsigned)kv_stride * HD * 2u;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
-    int voffK, voffV;
-    {
-        const int row = wave * 8 + (lane >> 3);                    // DMA piece = 8 rows x 128 B, lane-linear LDS image
-        voffK = row * 128 + (((lane & 7) ^ key_of<128>(row)) << 4);
-        voffV = row * 128 + (((lane & 7) ^ (((row >> 1) & 1) << 2)) << 4);
-    }
-    // Every stage is 2 KI DMA instructions (the counted vmcnt waits rely on it): tiles past the last one are "staged" from
-    // past the end of the slab — zero fill, no memory traffic.
-    auto stage_k = [&](int t, int slot, bool live) __attribute__((always_inline)) {
-        char* ks = smem + slot * KT;
-        const unsigned base = live ? ((unsigned)t * 64u + (unsigned)PFX) * 128u : slab;
-#pragma unroll
-        for (int i = 0; i < KI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16,
-                                                     voffK + (int)(base + (unsigned)i * 4096u), 0, 0, 0);
-    };
-    auto stage_v = [&](int t, int slot, bool live) __attribute__((always_inline)) {
-        char* vs = smem + (RING + slot) * KT;
-        const unsigned base = live ? ((unsigned)t * 64u + (unsigned)PFX) * 128u : slab;
-#pragma unroll
-        for (int i = 0; i < KI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_AS(vs + (i * 4 + wave) * 1024), 16,
-                                                     voffV + (int)(base + (unsigned)i * 4096u), 0, 0, 0);
-    };
-    const int kv_lo = kv_start ? max(min(kv_start[b], kv_len - 1), 0) : 0;
-    const int t_lo = kv_lo >> 6;
-    int kv_end = kv_len;
-    if (CAUSAL) kv_end = min(kv_len, max(qb * 128 + 127 + coff, kv_lo) + 1);
-    const int ntiles = (kv_end + 63) / 64;
-    // the first tiles' DMA goes out before anything else of the prologue
-    if (ntiles > t_lo) {
-        stage_k(t_lo, t_lo % 3, true);
-        stage_k(t_lo + 1, (t_lo + 1) % 3, t_lo + 1 < ntiles);
-        stage_v(t_lo, t_lo % 3, true);
-        stage_k(t_lo + 2, (t_lo + 2) % 3, t_lo + 2 < ntiles);       // these two are "the stage of S_(t_lo - 1)"
-        stage_v(t_lo + 1, (t_lo + 1) % 3, t_lo + 1 < ntiles);
-    }
-    bf16x8 qf[NKD];
-    {
-        const int qrow = min(q0 + l31, q_pad - 1);
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd)
-            qf[kd] = *reinterpret_cast<const bf16x8*>(Qp + (int64_t)qrow * HD + kd * 16 + h * 8);
-    }
-    f32x16 o[NDB];
-#pragma unroll
-    for (int d = 0; d < NDB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    // exp2(s - m) as v_pk_add_f32 (two scores per instruction) + v_exp_f32: v2's -m accumulator start costs sixteen registers
-    // this kernel does not have; the row sums are packed adds as well, so the VALU count per block is the same.
-    f32v2_t nm2 = {0.f, 0.f};                    // -(standing max) twice; 0 while the max is -inf
-    if (PFX) {                                   // key / value row 0 folded into the initial softmax state (see v2)
-        float part = 0.f;
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + kd * 16 + h * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                part = __builtin_fmaf(bf2f((bf16_t)qf[kd][e]), bf2f((bf16_t)kf[e]), part);
-        }
-        m_run = part + __shfl_xor(part, 32, 64);
-        l_run = h == 0 ? 1.0f : 0.f;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v4[4];
-                ld4(Vp + d * 32 + g * 8 + h * 4, v4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[d][g * 4 + r] = v4[r];
-            }
-        nm2 = f32v2_t{-m_run, -m_run};
-    }
-    // This wave works on tiles t_lo .. nt_w - 1 (wave-uniform: a causal wave stops at its own diagonal, a wave without query
-    // rows takes none); past them it still stages its DMA pieces and meets the barriers.
-    int nt_w = t_lo;
-    if (q0 < q_len) nt_w = CAUSAL ? min(ntiles, (max(q0 + 31 + coff, kv_lo) >> 6) + 1) : ntiles;
-
-    const int prow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2<->3 swapped
-    // LDS byte addresses of this lane's K fragment of k-step kd (block A; B = + 32 rows) and V fragment of d-block d (rows 0 ..).
-    // They point into the ring slot their next reader wants — K(j) / V(j - 1) in half 1 of tile j, K(j + 1) / V(j) in half 2 —
-    // and move on by one slot at every sync (six v_add per tile; the loop body exists once, not once per slot).
-    unsigned kaddr[NKD], vaddr[NDB];             // (block B's rows are 32 x 128 B further on, with the same swizzle key: an immediate)
-#pragma unroll
-    for (int kd = 0; kd < NKD; ++kd)
-        kaddr[kd] = (unsigned)(uintptr_t)LDS_AS(smem) + (unsigned)(prow * KRS + (((kd * 2 + h) ^ key_of<KRS>(prow)) << 4)) +
-                    (unsigned)(t_lo % 3) * KT;
-    {
-        const int i = lane & 15, r = 8 * h + (i >> 2);
-        const int col = 16 * ((lane >> 4) & 1) + 4 * (i & 3);
-        const int key4 = ((r >> 1) & 1) << 2;
-        const int vtr = r * KRS + ((((col >> 3) ^ key4) << 4) | ((col & 7) << 1));
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-            vaddr[d] = (unsigned)(uintptr_t)LDS_AS(smem) + (unsigned)(RING * KT + (vtr ^ (d << 6))) + (unsigned)((t_lo + 2) % 3) * KT;
-    }
-    // asm reads (no wait). K fragment of block BLK, k-step KD; V fragment from address a + OFF (16 kv rows)
-    auto kread = [&](auto BLK, auto KD, bf16x8& f) __attribute__((always_inline)) {
-        const unsigned a = kaddr[decltype(KD)::value];   // (a local: asm operands do not capture in a generic lambda)
-        DS_READ_B128(f, a, decltype(BLK)::value * 32 * KRS);
-    };
-    auto vread_at = [&](const unsigned a, auto OFF, bf16x8& f) __attribute__((always_inline)) {
-        tr4_t lo, hi;
-        DS_READ_TR64(lo, a, decltype(OFF)::value);
-        DS_READ_TR64(hi, a, decltype(OFF)::value + 4 * KRS);
-        f = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    };
-    f32x16 s[2];                    // scores of the current A block / B block
-    unsigned p[2][2][4];            // [block][16-kv step][word]: bf16 P of the block, the PV B operands
-    s[0] = zero16_c();
-    s[1] = zero16_c();
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) p[x][c][w] = 0u;
-    auto pfrag = [&](const unsigned (&pp)[4]) __attribute__((always_inline)) {
-        const u32x4 w = {pp[0], pp[1], pp[2], pp[3]};
-        return __builtin_bit_cast(bf16x8, w);
-    };
-    // the three pieces, one after the other (prologue, exact blocks, ends of the pipeline)
-    auto qk_block = [&](auto BLK, f32x16& so) __attribute__((always_inline)) {
-        static_for<NKD>([&](auto KD) __attribute__((always_inline)) {
-            constexpr int kd = decltype(KD)::value;
-            bf16x8 kf;
-            kread(BLK, KD, kf);
-            lgkm_wait<0>(kf);
-            so = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? zero16_c() : so, 0, 0, 0);
-        });
-    };
-    auto pv_block = [&](auto BLK, const unsigned (&pp)[2][4]) __attribute__((always_inline)) {
-        static_for<4>([&](auto VI) __attribute__((always_inline)) {
-            constexpr int v = decltype(VI)::value, d = v & 1, st = v >> 1;
-            bf16x8 vf;
-            vread_at(vaddr[d], std::integral_constant<int, (decltype(BLK)::value * 32 + st * 16) * KRS>{}, vf);
-            lgkm_wait<0>(vf);
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfrag(pp[st]), o[d], 0, 0, 0);
-        });
-    };
-    auto exp_pack = [&](const f32x16& si, unsigned (&pp)[2][4]) __attribute__((always_inline)) {
-        f32v2_t ps2 = {0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32v2_t t = f32v2_t{si[2 * i], si[2 * i + 1]} + nm2;
-            const f32v2_t e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-            ps2 += e;
-            pp[i >> 2][i & 3] = cvt_pk(e[0], e[1]);
-            __builtin_amdgcn_sched_barrier(0);   // (keeps the sixteen exponentials from being hoisted into sixteen live registers)
-        }
-        return ps2[0] + ps2[1];
-    };
-#ifdef ATTN_PIPE_TIMELINE
-    unsigned tl_t[7], tl_sum[6] = {0u, 0u, 0u, 0u, 0u, 0u}, tl_n = 0u, tl_loop0 = 0u, tl_loop1 = 0u;
-#endif
-    // The exact softmax of block X (the first tile, masked tiles, a failed lazy check): scores still in s[X] (raw: the
-    // max is subtracted in the softmax, so neither the next block's scores nor anything else depends on it), PV of every
-    // earlier block already in o. Mask, block max, re-base o / l when the max grew by more than 2^RESCALE_THR, exp, pack.
-    auto exact_block = [&](auto XC, const int kv0, const bool need_mask) __attribute__((always_inline)) {
-        constexpr int X = decltype(XC)::value;
-        if (need_mask) {
-            const int qi = q0 + l31;
-            const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + X * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                s[X][r] = (kv <= lim && kv >= kv_lo) ? s[X][r] : -INFINITY;
-            }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[X][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (!__all(mx - m_run <= RESCALE_THR)) {           // NaN (-inf - -inf) also lands here
-            const float m_new = fmaxf(m_run, mx);
-            const float m_nu = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_nu);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            nm2 = f32v2_t{-m_nu, -m_nu};
-        }
-        l_run += exp_pack(s[X], p[X]);
-    };
-    // One half: block X of tile j, always the same instruction stream.  QK^T of the next block (block X ^ 1 of the tile
-    // kaddr points into) -> s[X ^ 1];  PV of the previous block (block X ^ 1 of the tile vaddr points into) with p[X ^ 1];
-    // lazy softmax s[X] -> p[X] in the MFMAs' shadow. A block that needs the exact path gets it afterwards, over the lazy
-    // result (which may be garbage then — masked scores — and is not used). The wave's last half forms scores nobody reads
-    // (of the next tile, or of the zero-filled slot past the last one).
-    auto half = [&](auto XC, const int kv0, const bool exact, const bool need_mask) __attribute__((always_inline)) {
-        constexpr int X = decltype(XC)::value, NX = X ^ 1;
-        // fragment of MFMA m (even: QK^T k-step m / 2, odd: PV (d-block, kv step) m / 2) is read PFD bundles ahead of it
-        constexpr int PFD = ATTN_PIPE_PFD;
-        bf16x8 fr[8];
-        auto fread = [&](auto MI) __attribute__((always_inline)) {
-            constexpr int m = decltype(MI)::value;
-            if constexpr (m & 1) {
-                constexpr int v = m >> 1, d = v & 1, st = v >> 1;
-                vread_at(vaddr[d], std::integral_constant<int, (NX * 32 + st * 16) * KRS>{}, fr[m]);
-            } else {
-                kread(std::integral_constant<int, NX>{}, std::integral_constant<int, (m >> 1)>{}, fr[m]);
-            }
-        };
-        static_for<PFD>([&](auto MI) __attribute__((always_inline)) { fread(MI); });
-        f32v2_t ps2 = {0.f, 0.f}, e = {0.f, 0.f};
-        f32v2_t t = f32v2_t{s[X][0], s[X][1]} + nm2;
-        static_for<8>([&](auto II) __attribute__((always_inline)) {
-            constexpr int i = decltype(II)::value;
-            // LDS reads issued after this MFMA's fragment: those of MFMAs i + 1 .. i + PFD - 1 (1 for a K fragment, 2 for a V one)
-            constexpr int hi_m = (i + PFD - 1 < 7) ? i + PFD - 1 : 7;
-            constexpr int newer = (hi_m - i) + ((hi_m + 1) / 2 - (i + 1) / 2);
-            __builtin_amdgcn_sched_barrier(0);
-            lgkm_wait<newer>(fr[i]);
-            if constexpr (i & 1) {
-                constexpr int v = i >> 1, d = v & 1, st = v >> 1;
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pfrag(p[NX][st]), o[d], 0, 0, 0);
-            } else {
-                constexpr int kd = i >> 1;
-                s[NX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[kd], kd == 0 ? zero16_c() : s[NX], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // pair i: exponentials (its subtraction was the bundle before); pair i - 1: row sum and pack; pair i + 1: subtraction
-            // (the empty asm pins the work to this bundle: without it the optimiser sinks the whole lazy softmax into the
-            // branch behind the half that uses its result, out of the MFMAs' shadow)
-            f32v2_t ne = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-            asm volatile("" : "+v"(ne));
-            if constexpr (i > 0 && !(ATTN_PIPE_DIAG & 4)) {
-                ps2 += e;
-                unsigned w = cvt_pk(e[0], e[1]);
-                asm volatile("" : "+v"(w), "+v"(ps2));
-                p[X][(i - 1) >> 2][(i - 1) & 3] = w;
-            }
-            e = ne;
-            if constexpr (i < 7 && !(ATTN_PIPE_DIAG & 4)) {
-                t = f32v2_t{s[X][2 * i + 2], s[X][2 * i + 3]} + nm2;
-                asm volatile("" : "+v"(t));
-            }
-            if constexpr (i + PFD < 8 && !(ATTN_PIPE_DIAG & 8)) fread(std::integral_constant<int, i + PFD>{});
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        ps2 += e;
-        p[X][1][3] = cvt_pk(e[0], e[1]);
-        const float ps = ps2[0] + ps2[1];
-        // Lazy max: a lane whose partial row sum reaches 2^16 (or is inf / NaN) sends the wave through the exact path
-        if (exact || !__all(ps < 65536.0f)) exact_block(XC, kv0, need_mask);
-        else l_run += ps;
-    };
-    int sk = t_lo % 3;                           // ring slot of tile j
-    // S_j: the stage of S_j-2 (K(j + 1), V(j): read from here on) has landed, the one of S_j-1 stays in flight; then K(j + 3)
-    // goes over K(j) and V(j + 2) over V(j - 1), both dead since half 1, and the fragment addresses move on to K(j + 1), V(j)
-    auto sync_stage = [&](const int j) __attribute__((always_inline)) {
-        TLP(1)
-        if (!(ATTN_PIPE_DIAG & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * KI) : "memory");
-        TLP(2)
-        if (!(ATTN_PIPE_DIAG & 2)) __syncthreads();
-        TLP(3)
-        const int sv = sk == 0 ? 2 : sk - 1;     // slot of V(j - 1)
-        if (!(ATTN_PIPE_DIAG & 1)) {
-            stage_k(j + 3, sk, j + 3 < ntiles);
-            stage_v(j + 2, sv, j + 2 < ntiles);
-        }
-        const unsigned dk = sk == 2 ? (unsigned)(-2 * KT) : (unsigned)KT, dv = sk == 0 ? (unsigned)(-2 * KT) : (unsigned)KT;
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd) kaddr[kd] += dk;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) vaddr[d] += dv;
-        sk = sk == 2 ? 0 : sk + 1;
-        TLP(4)
-    };
-    // a tile this wave works on (FIRST: tile t_lo, compiled apart — no block before its block A, whose scores the prologue formed)
-    auto body = [&](auto FIRSTC, const int j) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(FIRSTC)::value;
-        const int kv0 = j * 64;
-        const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0 + coff);
-        TLP(0)
-        // half 1: QK^T(B_j) from K(j), PV(B_j-1) from V(j - 1), softmax(A_j)
-        if constexpr (FIRST) {
-            qk_block(std::integral_constant<int, 1>{}, s[1]);
-            exact_block(std::integral_constant<int, 0>{}, kv0, need_mask);
-        } else {
-            half(std::integral_constant<int, 0>{}, kv0, need_mask, need_mask);
-        }
-        sync_stage(j);
-        // half 2: QK^T(A_j+1) from K(j + 1), PV(A_j) from V(j), softmax(B_j)
-        half(std::integral_constant<int, 1>{}, kv0, FIRST || need_mask, need_mask);
-        TLP(5)
-#ifdef ATTN_PIPE_TIMELINE
-        if (!FIRST && !need_mask) {
-            for (int i = 0; i < 5; ++i) tl_sum[i] += tl_t[i + 1] - tl_t[i];
-            ++tl_n;
-        }
-#endif
-    };
-
-    if (ntiles > t_lo) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (Q and the folded key's loads are younger than the DMA: a counted wait would count them)
-        __syncthreads();
-        if (nt_w > t_lo) qk_block(std::integral_constant<int, 0>{}, s[0]);      // scores of A of the first tile
-#ifdef ATTN_PIPE_TIMELINE
-        tl_loop0 = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
-        int j = t_lo;
-        if (nt_w > t_lo) {
-            body(std::true_type{}, j);
-            for (++j; j < nt_w; ++j) body(std::false_type{}, j);
-            pv_block(std::integral_constant<int, 1>{}, p[1]);      // this wave's last block (vaddr -> V(nt_w - 1))
-        }
-        for (; j < ntiles; ++j) sync_stage(j);   // tiles of the workgroup past this wave's diagonal: its DMA pieces and the barriers
-#ifdef ATTN_PIPE_TIMELINE
-        tl_loop1 = (unsigned)__builtin_amdgcn_s_memtime();
-#endif
-        // nothing (not even a zero-fill stage) may still be writing this workgroup's LDS when it ends
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#ifdef ATTN_PIPE_TIMELINE
-    {
-        const bool writer = b == 0 && head == 0 && qb == nqb / 2;
-        if (writer && lane < 16) {
-            unsigned v = 0u;
-            for (int i = 0; i < 5; ++i) v = lane == i ? tl_sum[i] : v;
-            v = lane == 7 ? tl_n : lane == 9 ? (unsigned)ntiles : v;
-            v = lane == 10 ? tl_loop0 - tl_entry : lane == 11 ? tl_loop1 - tl_loop0 : lane == 12 ? (unsigned)__builtin_amdgcn_s_memtime() - tl_loop1 : v;
-            reinterpret_cast<unsigned*>(O + (int64_t)wave * ((int64_t)Hq * HD))[lane] = v;
-        }
-        if (b == 0 && head == 0 && qb == 0) return;
-    }
-#endif
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const int qi = q0 + l31;
-    if (qi < q_len) {
-        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        bf16_t* op = O + ((int64_t)b * q_len + qi) * ((int64_t)Hq * HD) + head * HD;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv, o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv};
-                st4(op + d * 32 + g * 8 + h * 4, v);
-            }
-    }
-}
-
 // returns false when this kernel does not apply (caller falls back to the register-staged kernel of attention.hip).
 // vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
@@ -979,15 +536,7 @@ bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O,
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
                        (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix)
-    if (hd == 64 && vrow && ATTN_PIPE) {
-        const int lds3 = 6 * kt;
-        if (causal)
-            hipLaunchKernelGGL((attn_bf16_v3_kernel<64, true>), grid, block, lds3, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
-                               (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix);
-        else
-            hipLaunchKernelGGL((attn_bf16_v3_kernel<64, false>), grid, block, lds3, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt,
-                               (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix);
-    } else if (hd == 64) {
+    if (hd == 64) {
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }
     }

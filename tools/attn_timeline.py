@@ -23,13 +23,8 @@ SEG = ["issue next tile's DMA", "K frag reads + QK^T MFMAs (issue)", "max (waits
        "s_barrier"]
 
 
-SEG_PIPE = ["stage DMA issue (+ address flip)", "16 bundles: MFMA | exp, sum, pack, fragment reads", "lazy check, l update",
-            "vmcnt: the previous stage landed", "s_barrier"]
-
-
 def main():
     hip.require_device(0)
-    pipe = os.environ.get("PIPE") == "1"      # -DATTN_PIPE=1 -DATTN_PIPE_TIMELINE build: v3's iteration (row-major V)
     dev, dt = "cuda:0", torch.bfloat16
     for name, B, Hq, Hkv, hd, n, causal in (("vit", 272, 16, 16, 64, 1025, False), ("prefill", 16, 32, 8, 64, 4718, True)):
         npad = (n + 63) // 64 * 64
@@ -37,19 +32,11 @@ def main():
         K = torch.randn(B, Hkv, npad, hd, device=dev).to(dt)
         Vt = torch.randn(B, Hkv, hd, npad, device=dev).to(dt)
         O = torch.zeros(B * n, Hq * hd, device=dev, dtype=dt)
-        Vr = Vt.transpose(2, 3).contiguous() if pipe else None
-        pfx = 1 if (pipe and not causal) else 0
-
-        def run():
-            if pipe:
-                ops.attention(Q, K, Vr, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal, v_row_major=True, kv_prefix=pfx)
-            else:
-                ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
         for _ in range(3):
-            run()
+            ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        run()
+        ops.attention(Q, K, Vt, O, B, Hq, Hkv, hd, n, npad, n, npad, causal=causal)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
@@ -63,16 +50,11 @@ def main():
             if ntl == 0:
                 print(f"wave {w}: no full tiles recorded {r}")
                 continue
-            seg = SEG_PIPE if pipe else SEG
-            per = [x / ntl for x in r[:5 if pipe else len(seg)]]
+            per = [x / ntl for x in r[:7]]
             tot = sum(per)
             print(f"wave {w}: {ntl} full tiles of {ntiles}; {tot:7.0f} cycles per kv tile (matrix pipe: 512 per wave); "
                   f"whole loop {total} ticks")
-            if pipe:
-                print(f"    entry -> loop {r[10]} ticks, loop {r[11]}, loop end -> O store {r[12]}")
-                print(f"    prologue stamps since entry: stage issued {r[13]}, Q loads issued {r[14]}, folded key done {r[15]}, "
-                      f"vmcnt(0) {r[5]}, barrier {r[6]}")
-            for nme, v in zip(seg, per):
+            for nme, v in zip(SEG, per):
                 print(f"    {v:7.0f}  {100 * v / tot:5.1f} %  {nme}")
 
 
