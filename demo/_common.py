@@ -20,7 +20,7 @@ def base_parser(description):
                     help="checkpoint directory (config.json + *.safetensors [+ tokenizer]); with --synthetic_weights a "
                          "size name: gar_1b | gar_8b | tiny")
     ap.add_argument("--data_type", choices=DATA_TYPE_CHOICES, default="bf16",
-                    help="bf16 | fp32; fp16 is refused with an explanation (no fp16 kernels)")
+                    help="bf16 | fp16 | fp32 (parity mode)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--max_num_tiles", type=int, default=16)

@@ -21,14 +21,8 @@ bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s);
 
-typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
-    f32v2 v = {lo, hi};
-    bf16v2 r = __builtin_convertvector(v, bf16v2);
-    return __builtin_bit_cast(unsigned int, r);
-}
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }
 
 // swizzle key of a row for a tile whose rows are RS bytes: makes 16 rows read at one logical chunk hit 16 distinct
 // 16-byte slots of the 256-byte LDS bank row ("attention LDS image").
@@ -147,7 +141,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int kd = 0; kd < NKD; ++kd) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * KRS + (((kd * 2 + h) ^ key) << 4));
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], s[blk], 0, 0, 0);
+                    s[blk] = MFMA_32x32x16(kf, qf[kd], s[blk]);
                 }
             }
             // masking (only on boundary tiles). register r of block blk <-> kv = kv0 + 32 blk + 16 (r>>3) + 8 h + (r&7)
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
                     for (int tt = 0; tt < 2; ++tt) {
                         const int c = (blk * 2 + tt) * 2 + h;
                         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + ((c ^ key) << 4));
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[blk][tt], o[d], 0, 0, 0);
+                        o[d] = MFMA_32x32x16(vf, pf[blk][tt], o[d]);
                     }
             }
         }

@@ -18,13 +18,8 @@
 #define TLA(i)
 #endif
 
-typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
 typedef float f32v2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) {
-    f32v2_t v = {lo, hi};
-    bf16v2_t r = __builtin_convertvector(v, bf16v2_t);
-    return __builtin_bit_cast(unsigned int, r);
-}
+__device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) { return pack_bf2(lo, hi); }
 
 __device__ __forceinline__ f32x16 zero16_c() {
     return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -283,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                 for (int kd = 0; kd < NKD; ++kd)
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk)
-                        s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[blk][kd], qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
+                        s[blk] = MFMA_32x32x16(kfa[blk][kd], qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk]);
 #else
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
@@ -291,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                     for (int kd = 0; kd < NKD; ++kd) {
                         const bf16x8 kf =
                             *reinterpret_cast<const bf16x8*>(ks + koff[blk] + (((kd * 2 + h) ^ kkey[blk]) << 4));
-                        s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk], 0, 0, 0);
+                        s[blk] = MFMA_32x32x16(kf, qf[kd], kd == 0 ? (NEGM ? negm : zero16) : s[blk]);
                     }
                 }
 #endif
@@ -371,11 +366,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                 if (ATTN_MFMA_ROWSUM) {
                     // ones[32 x 16] x P[16 kv x 32 q], four k-steps: every register of the result is the COMPLETE row sum of
                     // this lane's query column (both kv halves) of the bf16-rounded P — what the PV product divides by
-                    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-                    f32x16 ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[0][0], zero16, 0, 0, 0);
-                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[0][1], ls, 0, 0, 0);
-                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[1][0], ls, 0, 0, 0);
-                    ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[1][1], ls, 0, 0, 0);
+                    const bf16x8 ones = {H16_ONE, H16_ONE, H16_ONE, H16_ONE, H16_ONE, H16_ONE, H16_ONE, H16_ONE};
+                    f32x16 ls = MFMA_32x32x16(ones, pf[0][0], zero16);
+                    ls = MFMA_32x32x16(ones, pf[0][1], ls);
+                    ls = MFMA_32x32x16(ones, pf[1][0], ls);
+                    ls = MFMA_32x32x16(ones, pf[1][1], ls);
                     ps = ls[0];
                 }
             };
@@ -387,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
             // reaches 2^LAZY_LOG2 (or is inf / NaN) sends the wave through the exact path, which re-bases the max and
             // redoes the tile from the scores still in registers.
 #ifndef ATTN_LAZY_LOG2
-#define ATTN_LAZY_LOG2 16       /* 0: always the exact path (A/B) */
+#define ATTN_LAZY_LOG2 H16_MAX_LOG2       /* 0: always the exact path (A/B); 16, or 15 where P is stored as fp16 */
 #endif
             bool exact = ATTN_LAZY_LOG2 == 0 || t == t_lo || need_mask;                       // wave-uniform
             if (!exact) {
@@ -479,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                             const int c = (blk * 2 + tt) * 2 + h;
                             vf = *reinterpret_cast<const bf16x8*>(vs + row * 128 + ((c ^ key) << 4));
                         }
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[blk][tt], o[d], 0, 0, 0);
+                        o[d] = MFMA_32x32x16(vf, pf[blk][tt], o[d]);
                     }
             }
             TLA(5)

@@ -13,13 +13,8 @@
 
 #include "common.h"
 
-typedef __bf16 bf16v2_d __attribute__((ext_vector_type(2)));
 typedef float f32v2_d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk_d(float lo, float hi) {
-    f32v2_d v = {lo, hi};
-    bf16v2_d r = __builtin_convertvector(v, bf16v2_d);
-    return __builtin_bit_cast(unsigned int, r);
-}
+__device__ __forceinline__ unsigned int cvt_pk_d(float lo, float hi) { return pack_bf2(lo, hi); }
 
 typedef short tr4_d __attribute__((ext_vector_type(4)));
 // PV A-operand fragment (rows = d, k = 8 consecutive kv) out of a row-major V tile in LDS: two transposing reads, each a
@@ -227,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int kd = 0; kd < NKD; ++kd)
-                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+                s[blk] = MFMA_32x32x16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk]);
         if (kv0 + 64 > kv_len || kv0 < kv_lo) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -273,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_lds_kernel(const bf16_t* _
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
+                    o[d] = MFMA_32x32x16(vf[d][blk * 2 + tt], pf[blk][tt], o[d]);
         }
     }
     // ---- merge the four waves (LDS), one partial per block
@@ -429,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int kd = 0; kd < NKD; ++kd)
-                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk], 0, 0, 0);
+                    s[blk] = MFMA_32x32x16(kf[blk][kd], qf[kd], kd == 0 ? zero16 : s[blk]);
         }
         const int kv0 = t * 64;
         if (kv0 + 64 > kv_len || kv0 < kv_lo) {
@@ -492,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void decode_attn_lds128_kernel(const bf16_t
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][blk * 2 + tt], pf[blk][tt], o[d], 0, 0, 0);
+                    o[d] = MFMA_32x32x16(vf[d][blk * 2 + tt], pf[blk][tt], o[d]);
         }
     }
     // ---- merge the four waves (LDS), one partial per block — as in decode_attn_lds_kernel

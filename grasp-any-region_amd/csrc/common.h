@@ -17,15 +17,46 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;   // MFMA bf16 operand
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
+// The library's 16-bit element type: bfloat16, or — in the twin build -DGAR_HALF_F16=1 (libgar_hip_f16.so, the reference's
+// --data_type fp16) — IEEE binary16. Storage type, layouts, kernels and entry points are the same; only these conversions, the
+// matrix instruction's operand format and two range constants differ. "bf16" in names below means "the 16-bit type".
+#ifndef GAR_HALF_F16
+#define GAR_HALF_F16 0
+#endif
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+#if GAR_HALF_F16
+typedef _Float16 h16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8_hw_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float unpk_lo(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float unpk_hi(unsigned int w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+// fp32 -> fp16, round to nearest even (overflow -> inf, as the reference's .half())
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+    const f32x2_hw_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, h16x2_hw_t));
+}
+#define MFMA_32x32x16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_hw_t, a), __builtin_bit_cast(h16x8_hw_t, b), c, 0, 0, 0)
+#define MFMA_16x16x32(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_hw_t, a), __builtin_bit_cast(h16x8_hw_t, b), c, 0, 0, 0)
+#define H16_ONE 0x3C00
+#define H16_MAX_LOG2 15      /* largest power of two a stored softmax weight may reach (fp16 ends at 65504) */
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned int)v) << 16); }
+__device__ __forceinline__ float unpk_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float unpk_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 // fp32 -> bf16, round to nearest even, NaN quieted: gfx950's v_cvt_pk_bf16_f32 (the integer formulation costs ~10
 // instructions per element, four of them exec-mask juggling for the NaN case — it dominated the GEMM epilogue)
 typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
     const f32x2_hw_t v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_hw_t));
 }
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define H16_ONE 0x3F80
+#define H16_MAX_LOG2 16
+#endif
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct DT;
@@ -45,8 +76,8 @@ __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
 }
 __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
     uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = unpk_lo(t.x); v[1] = unpk_hi(t.x);
+    v[2] = unpk_lo(t.y); v[3] = unpk_hi(t.y);
 }
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -61,10 +92,10 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 }
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    v[0] = unpk_lo(t.x); v[1] = unpk_hi(t.x);
+    v[2] = unpk_lo(t.y); v[3] = unpk_hi(t.y);
+    v[4] = unpk_lo(t.z); v[5] = unpk_hi(t.z);
+    v[6] = unpk_lo(t.w); v[7] = unpk_hi(t.w);
 }
 __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
     reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);

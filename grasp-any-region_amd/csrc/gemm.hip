@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const gar_gemm_params
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA_16x16x32(wf[j], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
     __builtin_amdgcn_s_setprio(1);                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-            acc[(mh) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[(mh) * 4 + i][j], 0, 0, 0); \
+            acc[(mh) * 4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[(mh) * 4 + i][j]); \
     __builtin_amdgcn_s_setprio(0);
 #ifdef PP_TIMELINE   /* diagnostic build (tools/gemm_timeline.py): shader-clock stamps around every barrier */
 #if PP_TIMELINE >= 2   /* light: only the stamps around phase 0 (barriers 7 -> 0), so the other phases run undisturbed */
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         const unsigned int w[4] = {aux[k].x, aux[k].y, aux[k].z, aux[k].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                            const float lo = unpk_lo(w[e]), hi = unpk_hi(w[e]);
                             if (EPI == GAR_EPI_BIAS_SCALE_RES) {
                                 o[2 * e] = lo + gam8[2 * e] * o[2 * e];
                                 o[2 * e + 1] = hi + gam8[2 * e + 1] * o[2 * e + 1];
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             const u32x4 w = aux[i % (AH + 1)][t];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                                const float lo = unpk_lo(w[e]), hi = unpk_hi(w[e]);
                                 if (EPI == GAR_EPI_BIAS_SCALE_RES) {
                                     o[2 * e] = lo + gam8[2 * e] * o[2 * e];
                                     o[2 * e + 1] = hi + gam8[2 * e + 1] * o[2 * e + 1];
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float lo = __uint_as_float(pk[e] << 16), hi = __uint_as_float(pk[e] & 0xffff0000u);
+                                const float lo = unpk_lo(pk[e]), hi = unpk_hi(pk[e]);
                                 s1 += lo + hi;
                                 s2 = __builtin_fmaf(lo, lo, s2);
                                 s2 = __builtin_fmaf(hi, hi, s2);
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned w = bias_cur[j >> 1][((j & 1) * 4 + r) >> 1];
-                    bv[j][r] = (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                    bv[j][r] = (r & 1) ? unpk_hi(w) : unpk_lo(w);
                 }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
-                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[4 + i][j], 0, 0, 0);        \
+                acc[4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[4 + i][j]);        \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
             __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                                                       \
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned w = bias_cur[j >> 1][((j & 1) * 4 + r) >> 1];
-                    bv[j][r] = !BIAS_INIT ? 0.f : ((r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16));
+                    bv[j][r] = !BIAS_INIT ? 0.f : ((r & 1) ? unpk_hi(w) : unpk_lo(w));
                 }
 #pragma unroll
             for (int i = 0; i < 8; ++i)

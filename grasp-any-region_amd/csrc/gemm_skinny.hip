@@ -164,16 +164,16 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
         for (int mt = 0; mt < MT; ++mt) {
             bf16x8 x0 = xr0[mt], x1 = xr1[mt];
             if (NORM == 2) {
-                ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, ssm[mt], 0, 0, 0);
-                ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, ssm[mt], 0, 0, 0);
+                ssm[mt] = MFMA_16x16x32(x0, x0, ssm[mt]);
+                ssm[mt] = MFMA_16x16x32(x1, x1, ssm[mt]);
             }
             if (NORM == 1) {
                 const u32x4 ua = __builtin_bit_cast(u32x4, x0), ub = __builtin_bit_cast(u32x4, x1);
                 u32x4 pa, pb;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float a0 = __uint_as_float(ua[e] << 16), a1 = __uint_as_float(ua[e] & 0xffff0000u);
-                    const float b0 = __uint_as_float(ub[e] << 16), b1 = __uint_as_float(ub[e] & 0xffff0000u);
+                    const float a0 = unpk_lo(ua[e]), a1 = unpk_hi(ua[e]);
+                    const float b0 = unpk_lo(ub[e]), b1 = unpk_hi(ub[e]);
                     ssq[mt] += a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1;
                     pa[e] = pack_bf2(a0 * ga[2 * e], a1 * ga[2 * e + 1]);
                     pb[e] = pack_bf2(b0 * gb[2 * e], b1 * gb[2 * e + 1]);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[t], x0, acc[t][mt], 0, 0, 0);
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t], x1, acc[t][mt], 0, 0, 0);
+                acc[t][mt] = MFMA_16x16x32(w0[t], x0, acc[t][mt]);
+                acc[t][mt] = MFMA_16x16x32(w1[t], x1, acc[t][mt]);
             }
         }
     };
@@ -222,14 +222,14 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
                 x0 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0);
                 x1 = *reinterpret_cast<const bf16x8*>(xp[mt] + k0 + 8);
                 if (NORM == 2) {
-                    ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, ssm[mt], 0, 0, 0);
-                    ssm[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, ssm[mt], 0, 0, 0);
+                    ssm[mt] = MFMA_16x16x32(x0, x0, ssm[mt]);
+                    ssm[mt] = MFMA_16x16x32(x1, x1, ssm[mt]);
                 }
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[t], x0, acc[t][mt], 0, 0, 0);
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[t], x1, acc[t][mt], 0, 0, 0);
+                acc[t][mt] = MFMA_16x16x32(w0[t], x0, acc[t][mt]);
+                acc[t][mt] = MFMA_16x16x32(w1[t], x1, acc[t][mt]);
             }
         }
     };

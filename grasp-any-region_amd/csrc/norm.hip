@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, T* _
 // wave — 8 x 16 B per lane here (R = 4 rows of D <= 1024, R = 2 of D <= 2048) against 4 with fp32-cached rows. Same
 // arithmetic, in the same order, as norm_kernel: a row's result does not depend on its place in the wave.
 __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    v[0] = unpk_lo(t.x); v[1] = unpk_hi(t.x);
+    v[2] = unpk_lo(t.y); v[3] = unpk_hi(t.y);
+    v[4] = unpk_lo(t.z); v[5] = unpk_hi(t.z);
+    v[6] = unpk_lo(t.w); v[7] = unpk_hi(t.w);
 }
 
 template <bool RMS, int NC, int R>

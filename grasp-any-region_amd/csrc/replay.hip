@@ -291,10 +291,10 @@ template <> struct Raw8<bf16_t> {
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
     __device__ __forceinline__ void get(float (&o)[8]) const {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+        o[0] = unpk_lo(v.x); o[1] = unpk_hi(v.x);
+        o[2] = unpk_lo(v.y); o[3] = unpk_hi(v.y);
+        o[4] = unpk_lo(v.z); o[5] = unpk_hi(v.z);
+        o[6] = unpk_lo(v.w); o[7] = unpk_hi(v.w);
     }
 };
 template <> struct Raw8<float> {

@@ -14,18 +14,14 @@ from PIL import Image
 
 from . import dp, rle
 
-TORCH_DTYPE_MAP = dict(bf16=torch.bfloat16, fp32=torch.float32)
+TORCH_DTYPE_MAP = dict(bf16=torch.bfloat16, fp16=torch.float16, fp32=torch.float32)
 DATA_TYPE_CHOICES = ["fp16", "bf16", "fp32"]   # the reference CLIs' choices (demo/gar_with_mask.py:44)
 
 
 def resolve_data_type(name):
-    """--data_type of the reference CLIs. fp16 is parsed (same flag surface) and refused here with the reason:
-    the gfx950 kernels compute in bf16 (MFMA, fp32 accumulate) or fp32 (parity mode); there is no fp16 path and a
-    silent bf16 substitution would change the results the flag asks for."""
-    if name == "fp16":
-        raise SystemExit("--data_type fp16 is not supported by the MI355X path: the HIP kernels compute in bf16 "
-                         "(default, what the released GAR checkpoints are stored in) or fp32; use --data_type bf16 "
-                         "or fp32")
+    """--data_type of the reference CLIs (demo/gar_with_mask.py:41-45): bf16 (default, what the released checkpoints are
+    stored in), fp16 (the twin library libgar_hip_f16.so: the same kernels with IEEE binary16 as the 16-bit element type)
+    or fp32 (parity mode)."""
     return TORCH_DTYPE_MAP[name]
 
 
@@ -37,7 +33,7 @@ def base_parser(description, default_model, default_cache, default_images):
     ap.add_argument("--anno_file", required=True, help="annotation file path")
     ap.add_argument("--image_folder", default=default_images, help="the folder of images")
     ap.add_argument("--data_type", choices=DATA_TYPE_CHOICES, default="bf16",
-                    help="bf16 | fp32; fp16 is refused with an explanation (no fp16 kernels)")
+                    help="bf16 | fp16 | fp32 (parity mode)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default=None, help="default: cuda:LOCAL_RANK")
     ap.add_argument("--max_num_tiles", type=int, default=16)

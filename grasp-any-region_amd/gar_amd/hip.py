@@ -10,6 +10,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GAR_HIP_LIB: load another build of the same sources (diagnostic builds of tools/: timeline stamps, de-phased GEMM)
 LIB_PATH = os.environ.get("GAR_HIP_LIB") or os.path.join(_HERE, "libgar_hip.so")
+# The twin build of the same sources whose 16-bit element type is IEEE binary16 (csrc/common.h, -DGAR_HALF_F16=1): the
+# reference's `--data_type fp16` (demo/gar_with_mask.py:41-45). Same entry points; dtype code 1 means "the 16-bit type" there.
+LIB_F16_PATH = os.environ.get("GAR_HIP_LIB_F16") or os.path.join(_HERE, "libgar_hip_f16.so")
 
 GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
@@ -82,14 +85,17 @@ SIGNATURES = {
 }
 
 _lib = None
+_lib_f16 = None
+_last = None        # the library of the most recent call (whose gar_last_error() a failing rc refers to)
 
 
-def load_library(path: str = None):
+def load_library(path: str = None, f16: bool = False):
     """Loads the shared library and binds every symbol of include/gar_hip.h; raises if anything is missing."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    path = path or LIB_PATH
+    global _lib, _lib_f16
+    cached = _lib_f16 if f16 else _lib
+    if cached is not None and path is None:
+        return cached
+    path = path or (LIB_F16_PATH if f16 else LIB_PATH)
     if not os.path.exists(path):
         raise GarError(f"{path} not found — build it with `python __graft_entry__.py` or "
                        f"`make -C grasp-any-region_amd/csrc` (there is no CPU/PyTorch fallback)")
@@ -104,17 +110,23 @@ def load_library(path: str = None):
     v = lib.gar_abi_version()
     if v != ABI_VERSION:
         raise GarError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
-    _lib = lib
+    if f16:
+        _lib_f16 = lib
+    else:
+        _lib = lib
     return lib
 
 
-def lib():
-    return load_library()
+def lib(dt: torch.dtype = None):
+    """The library that serves element type `dt`: libgar_hip_f16.so for torch.float16, libgar_hip.so otherwise."""
+    global _last
+    _last = load_library(f16=(dt == torch.float16))
+    return _last
 
 
 def check(rc: int, what: str = ""):
     if rc != 0:
-        msg = lib().gar_last_error()
+        msg = (_last or lib()).gar_last_error()
         raise GarError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 
@@ -132,9 +144,9 @@ def num_cus(device_index: int = 0) -> int:
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return GAR_F32
-    if dt == torch.bfloat16:
+    if dt == torch.bfloat16 or dt == torch.float16:      # the 16-bit type of the library lib(dt) returns
         return GAR_BF16
-    raise GarError(f"unsupported dtype {dt} (float32 parity mode or bfloat16)")
+    raise GarError(f"unsupported dtype {dt} (float32 parity mode, bfloat16 or float16)")
 
 
 def ptr(t) -> int:

@@ -27,6 +27,9 @@ from .weights import LM, PJ, VT, check_weights, load_weights, normalize_checkpoi
 LOG2E = 1.4426950408889634
 
 
+# 16-bit element types: the fused bf16 kernels serve both (libgar_hip.so / its twin libgar_hip_f16.so, hip.lib(dtype))
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
 class _PendingGeneration:
     """What generate_begin hands to generate_finish: the KV state (slot) the prompt was prefilled into and the loop's settings."""
     def __init__(self, **kw):
@@ -413,7 +416,7 @@ class GARModel:
         # DMA): column ((tensor*3 + c)*4 + ky//4)*64 + (ky%4)*16 + kx; zero in the slots no pixel of the patch maps to
         self.w_patch_gather = None
         P_ = v.patch_size
-        Kg = ops.patch_embed_k(v.img_size, P_) if self.dtype == torch.bfloat16 else 0
+        Kg = ops.patch_embed_k(v.img_size, P_) if self.dtype in HALF_DTYPES else 0
         if Kg:
             wg = torch.zeros(D, 2, 3, 4, 4, 16, dtype=torch.float32, device=wcat.device)
             for ti, key in enumerate((VT + "patch_embed.proj.weight", "mask_patch_embedding.weight")):
@@ -433,7 +436,7 @@ class GARModel:
         H, hd = v.num_heads, v.head_dim
         if hd > 128:
             raise hip.GarError(f"vision head_dim {hd} > 128 is not built")
-        native = (64, 96, 128) if self.dtype == torch.bfloat16 else (64, 128)
+        native = (64, 96, 128) if self.dtype in HALF_DTYPES else (64, 128)
         self.v_hd = hdp = hd if hd in native else (64 if hd < 64 else 128)
 
         def pad_qkv(w):          # [3*H*hd, ...] -> [3*H*hdp, ...]
@@ -451,7 +454,7 @@ class GARModel:
             out[:, :, :hd] = w.reshape(w.shape[0], H, hd)
             return out.reshape(w.shape[0], H * hdp)
 
-        fold = self.dtype == torch.bfloat16
+        fold = self.dtype in HALF_DTYPES
         plain = not fold or self.keep_plain_weights
 
         def fold_ln(w, bias, gamma, beta):
@@ -596,7 +599,7 @@ class GARModel:
         qkv = Vt = vrow = None             # only the paths that need them allocate them (2.4 GB + 0.9 GB at 387 tiles)
         # bf16 at sizes the ping-pong GEMM takes: q / k leave the qkv GEMM already rotated, scaled and in attention
         # layout (GAR_EPI_QKV_ROPE), only V still needs its transpose; otherwise gemm + vit_qkv_post
-        fused = self.dtype == torch.bfloat16
+        fused = self.dtype in HALF_DTYPES
         # bf16: V stays row-major [Tt, H, Npad, hd] (zero-initialised like Q / K: pad rows must be finite)
         Vr = self._buf(key, "Vr", (Tt, H, Npad, hd), zero=True) if fused and self.VIT_V_ROW_MAJOR else None
         f1 = self._buf(key, "f1", (Tt * N, max(Dm, C_l)))
@@ -885,7 +888,7 @@ class GARModel:
         cos, sin = self._llm_rope(Smax)
         q_scale = (hd ** -0.5) * LOG2E
         lp = st["left_pad"][b0:b0 + B]
-        bf16 = self.dtype == torch.bfloat16
+        bf16 = self.dtype in HALF_DTYPES
         has_folded = "qkv_f" in self.layers[0]
         use_folded_w = has_folded and (self.FOLD_NORMS or "qkv" not in self.layers[0])         # bf16 keeps only these by default
         # Folded RMSNorms (bf16, tile-GEMM sized passes): qkv and gate/up read the residual stream h with W diag(g) and scale
@@ -1025,7 +1028,7 @@ class GARModel:
         nsplit = max(1, min(self.DECODE_ATTN_MAX_SPLITS, self.DECODE_ATTN_BLOCKS // max(1, B * Hkv)))
         dws = self._buf(key, "attn_ws", (ops.attention_decode_workspace(B, Hq, hd, nsplit),), torch.uint8)
         ops.embed_lookup(st["cur"], self.E, h)
-        bf16 = self.dtype == torch.bfloat16
+        bf16 = self.dtype in HALF_DTYPES
         use_folded_w = "qkv_f" in self.layers[0] and (self.FOLD_NORMS or "qkv" not in self.layers[0])
         # how the two RMSNorms of a layer reach their GEMVs:
         #   folded  (bf16, B <= 64): gain in the weight (qkv_f / gu_f), row sums of squares off the matrix pipe inside the GEMV

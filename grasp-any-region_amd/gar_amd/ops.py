@@ -83,14 +83,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         # HIP events on the launch stream around this one kernel (bench.py roofline; never inside graph capture)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
+        check(lib(a.dtype).gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
         e1.record()
         # M <= 64: the weight-streaming skinny kernels (decode GEMVs, lm_head, the pruned prefill tail) — HBM-bound, priced on
         # bytes; everything larger is the MFMA-bound tile GEMM family
         kind = ("gemm_skinny" if M <= 64 else "gemm_tile") + ("_bf16" if a.dtype == torch.bfloat16 else "_f32")
         prof.append((KERNEL_PHASE + kind, 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), e0, e1))
         return out
-    check(lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
+    check(lib(a.dtype).gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
     return out
 
 
@@ -127,7 +127,7 @@ def splitk_residual_rmsnorm(partial: torch.Tensor, h: torch.Tensor, w: Optional[
     S, M, D = partial.shape
     assert h.is_contiguous() and h.shape == (M, D) and (out is None or (out.is_contiguous() and out.shape == (M, D)))
     _timed("splitk_reduce", partial.numel() * 4 + (2 + (out is not None)) * M * D * h.element_size(), lambda: check(
-        lib().gar_splitk_residual_rmsnorm(dtype_code(h.dtype), ptr(partial), S, ptr(h), ptr(w), ptr(out), M, D, eps,
+        lib(h.dtype).gar_splitk_residual_rmsnorm(dtype_code(h.dtype), ptr(partial), S, ptr(h), ptr(w), ptr(out), M, D, eps,
                                           stream()), "gar_splitk_residual_rmsnorm"))
     return h
 
@@ -136,7 +136,7 @@ def mask_decode(mask: torch.Tensor, out: torch.Tensor, prompt_numbers: int):
     """out = (clamp(round((mask + 1) / 2 * 255), 0, P) != P) in the tensor's dtype (modeling_gar.py:315-327)."""
     _chk(mask, "mask")
     assert out.shape == mask.shape and out.dtype == mask.dtype and out.is_contiguous()
-    check(lib().gar_mask_decode(dtype_code(mask.dtype), ptr(mask), ptr(out), mask.numel(), prompt_numbers, stream()),
+    check(lib(mask.dtype).gar_mask_decode(dtype_code(mask.dtype), ptr(mask), ptr(out), mask.numel(), prompt_numbers, stream()),
           "gar_mask_decode")
     return out
 
@@ -162,7 +162,7 @@ def patch_embed(pixel: torch.Tensor, maskbin: torch.Tensor, w_gather: torch.Tens
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().gar_patch_embed(dtype_code(pixel.dtype), ptr(pixel), ptr(maskbin), ptr(w_gather), ptr(pos), ptr(x), T, img,
+    rc = lib(pixel.dtype).gar_patch_embed(dtype_code(pixel.dtype), ptr(pixel), ptr(maskbin), ptr(w_gather), ptr(pos), ptr(x), T, img,
                                patch, D, x.shape[1], token_offset, stream())
     if rc == hip.ERR_UNSUPPORTED:
         return False
@@ -179,14 +179,14 @@ def patch_im2col(pixel: torch.Tensor, mask: Optional[torch.Tensor], out: torch.T
     _chk(pixel, "pixel")
     T, c, img, _ = pixel.shape
     assert c == 3 and (mask is None or mask.shape == pixel.shape)
-    check(lib().gar_patch_im2col(dtype_code(pixel.dtype), ptr(pixel), ptr(mask), ptr(out), T, img, patch, out.shape[-1],
+    check(lib(pixel.dtype).gar_patch_im2col(dtype_code(pixel.dtype), ptr(pixel), ptr(mask), ptr(out), T, img, patch, out.shape[-1],
                                  prompt_numbers, stream()), "gar_patch_im2col")
     return out
 
 
 def cls_pos_fill(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor):
     T, tokens, D = x.shape
-    check(lib().gar_cls_pos_fill(dtype_code(x.dtype), ptr(x), ptr(cls), ptr(pos), T, tokens, D, stream()),
+    check(lib(x.dtype).gar_cls_pos_fill(dtype_code(x.dtype), ptr(x), ptr(cls), ptr(pos), T, tokens, D, stream()),
           "gar_cls_pos_fill")
 
 
@@ -194,7 +194,7 @@ def tokens_add(x: torch.Tensor, add: torch.Tensor, token_offset: int):
     """x[t, token_offset + p, :] += add[t, p, :] (modeling_perception_lm.py:195-196, ``x + mask_embeds...``)."""
     T, tokens_out, D = x.shape
     assert x.is_contiguous() and add.is_contiguous() and add.dtype == x.dtype and add.shape[0] == T and add.shape[2] == D
-    check(lib().gar_tokens_add(dtype_code(x.dtype), ptr(x), ptr(add), T, add.shape[1], tokens_out, token_offset, D, stream()),
+    check(lib(x.dtype).gar_tokens_add(dtype_code(x.dtype), ptr(x), ptr(add), T, add.shape[1], tokens_out, token_offset, D, stream()),
           "gar_tokens_add")
 
 
@@ -212,7 +212,7 @@ def layernorm(x, w, b, eps: float, out=None):
     out = x if out is None else out
     M, D, ldx = _rows(x)
     _, _, ldy = _rows(out)
-    check(lib().gar_layernorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), ptr(b), M, D, ldx, ldy, eps, stream()),
+    check(lib(x.dtype).gar_layernorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), ptr(b), M, D, ldx, ldy, eps, stream()),
           "gar_layernorm")
     return out
 
@@ -221,7 +221,7 @@ def rmsnorm(x, w, eps: float, out=None):
     out = x if out is None else out
     M, D, ldx = _rows(x)
     _, _, ldy = _rows(out)
-    check(lib().gar_rmsnorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), M, D, ldx, ldy, eps, stream()),
+    check(lib(x.dtype).gar_rmsnorm(dtype_code(x.dtype), ptr(x), ptr(out), ptr(w), M, D, ldx, ldy, eps, stream()),
           "gar_rmsnorm")
     return out
 
@@ -231,7 +231,7 @@ def row_rstd(x, eps: float, rms: bool, out):
     norm whose scaling half is folded into the next GEMM (``gemm(..., row_scale=out)``)."""
     M, D, ldx = _rows(x)
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= M
-    check(lib().gar_row_rstd(dtype_code(x.dtype), ptr(x), M, D, ldx, eps, int(rms), ptr(out), stream()), "gar_row_rstd")
+    check(lib(x.dtype).gar_row_rstd(dtype_code(x.dtype), ptr(x), M, D, ldx, eps, int(rms), ptr(out), stream()), "gar_row_rstd")
     return out
 
 
@@ -246,7 +246,7 @@ def row_stats_finalize(stats, D: int, eps: float, rms: bool, out):
 
 
 def vit_qkv_post(qkv, sin, cos, Q, K, Vt, T, N, npt, H, hd, Npad, q_scale):
-    check(lib().gar_vit_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(sin), ptr(cos), ptr(Q), ptr(K), ptr(Vt), T, N, npt,
+    check(lib(qkv.dtype).gar_vit_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(sin), ptr(cos), ptr(Q), ptr(K), ptr(Vt), T, N, npt,
                                  H, hd, Npad, q_scale, stream()), "gar_vit_qkv_post")
 
 
@@ -301,7 +301,7 @@ def gemm_qkv_rope(a, w, bias, v_out, Q, K, sin, cos, heads, hd, tokens, tokens_p
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
+    rc = lib(a.dtype).gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
     if rc == hip.ERR_UNSUPPORTED:
         return False
     check(rc, "gar_gemm(QKV_ROPE)")
@@ -347,7 +347,7 @@ def gemm_qkv_rope_llm(a, w, Q, Kc, Vc, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, 
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
+    rc = lib(a.dtype).gar_gemm(dtype_code(a.dtype), C.byref(p), stream())
     if rc == hip.ERR_UNSUPPORTED:
         return False
     check(rc, "gar_gemm(QKV_ROPE_LLM)")
@@ -358,7 +358,7 @@ def gemm_qkv_rope_llm(a, w, Q, Kc, Vc, cos, sin, B, S, Spad, Hq, Hkv, hd, Smax, 
 
 
 def vit_v_transpose(v, Vt, T, N, H, hd, Npad):
-    check(lib().gar_vit_v_transpose(dtype_code(v.dtype), ptr(v), ptr(Vt), T, N, H, hd, Npad, stream()),
+    check(lib(v.dtype).gar_vit_v_transpose(dtype_code(v.dtype), ptr(v), ptr(Vt), T, N, H, hd, Npad, stream()),
           "gar_vit_v_transpose")
 
 
@@ -366,7 +366,7 @@ def llm_qkv_post(qkv, cos, sin, Q, Kc, Vc, B, S, Spad, Hq, Hkv, hd, Smax, pos0, 
                  strip_order: bool = False):
     """``Kc``, ``Vc`` [B, Hkv, Smax, hd]. ``left_pad`` int32 [B] (device) or None: first real row of each sequence of a
     left-padded batch. ``strip_order``: the q / k head columns of ``qkv`` are in :func:`llm_qkv_weight_order`'s order."""
-    check(lib().gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vc), B, S,
+    check(lib(qkv.dtype).gar_llm_qkv_post(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Q), ptr(Kc), ptr(Vc), B, S,
                                  Spad, Hq, Hkv, hd, Smax, pos0, ptr(pos_dev), ptr(left_pad), q_scale, int(strip_order),
                                  stream()), "gar_llm_qkv_post")
 
@@ -382,12 +382,12 @@ def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, caus
     kind = "attn_causal" if causal else "attn_full"
     if v_row_major:
         _timed(kind, 0.0, lambda: check(
-            lib().gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+            lib(Q.dtype).gar_attention_vrow(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
                                      kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), int(kv_prefix),
                                      stream()), "gar_attention_vrow"), flops=4.0 * B * Hq * hd * pairs)
         return
     _timed(kind, 0.0, lambda: check(
-        lib().gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
+        lib(Q.dtype).gar_attention(dtype_code(Q.dtype), ptr(Q), ptr(K), ptr(Vt), ptr(O), B, Hq, Hkv, hd, q_len, q_pad,
                             kv_len, kv_stride, int(causal), ptr(kv_len_dev), ptr(kv_start), stream()), "gar_attention"),
         flops=4.0 * B * Hq * hd * pairs)
 
@@ -398,7 +398,7 @@ def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits,
     ``q = Q[:, :, S - 1]`` of a prefill's Q [B, Hq, Spad, hd] and ``q_stride = Spad * hd`` the last prompt row is read in place."""
     # (bytes: the kv length lives in device memory; bench.py prices a launch at B * Hkv * kv_len * hd * 2 tensors * 2 B)
     _timed("attn_decode", 0.0, lambda: check(
-        lib().gar_attention_decode(dtype_code(q.dtype), ptr(q), int(q_stride), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
+        lib(q.dtype).gar_attention_decode(dtype_code(q.dtype), ptr(q), int(q_stride), ptr(Kc), ptr(Vc), ptr(O), B, Hq, Hkv, hd, Smax,
                                    ptr(kv_len_dev), ptr(kv_start), max_splits, ptr(workspace), stream()),
         "gar_attention_decode"))
 
@@ -412,7 +412,7 @@ def attention_decode_qkv(qkv, cos, sin, Kc, Vc, O, B, Hq, Hkv, hd, Smax, pos_dev
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().gar_attention_decode_qkv(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Kc), ptr(Vc), ptr(O), B, Hq,
+    rc = lib(qkv.dtype).gar_attention_decode_qkv(dtype_code(qkv.dtype), ptr(qkv), ptr(cos), ptr(sin), ptr(Kc), ptr(Vc), ptr(O), B, Hq,
                                         Hkv, hd, Smax, ptr(pos_dev), ptr(left_pad), q_scale, int(strip_order), max_splits,
                                         ptr(workspace), stream())
     if rc == hip.ERR_UNSUPPORTED:
@@ -432,7 +432,7 @@ def pool2x2(x, y, g: int, in_tile_tokens: int = 0, in_token_offset: int = 0):
     """x [T, in_tile_tokens, C] (tokens in_token_offset .. +g*g of each tile are the g x g grid) -> y [T, (g/2)^2, C]"""
     T, Cc = y.shape[0], y.shape[-1]
     _timed("pool2x2", (T * g * g * Cc + y.numel()) * x.element_size(), lambda: check(
-        lib().gar_pool2x2(dtype_code(x.dtype), ptr(x), ptr(y), T, g, Cc, in_tile_tokens, in_token_offset, stream()),
+        lib(x.dtype).gar_pool2x2(dtype_code(x.dtype), ptr(x), ptr(y), T, g, Cc, in_tile_tokens, in_token_offset, stream()),
         "gar_pool2x2"))
     return y
 
@@ -454,7 +454,7 @@ def pool_assemble(input_ids, slot, E, proj, out, tiles_per_sample, g, in_tile_to
     n_img = B * tiles_per_sample * (g // 2) ** 2
     # algorithmic bytes: the grid rows of the projector output read once + the sequence written once
     _timed("pool_assemble", (4 * n_img * C_ + out.numel()) * out.element_size(), lambda: check(
-        lib().gar_pool_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(proj), ptr(out), B, S, C_,
+        lib(E.dtype).gar_pool_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(proj), ptr(out), B, S, C_,
                                 tiles_per_sample, g, in_tile_tokens, in_token_offset, E.shape[0], stream()),
         "gar_pool_assemble"))
 
@@ -463,7 +463,7 @@ def roi_replay_inplace(embeds, spans, rank_pos, jobs, n_crop, P, Cc, S, sampling
     """batched RoI replay reading the pooled features from the image-token rows of ``embeds`` (see pool_assemble)."""
     n = jobs.numel() // 40
     _timed("roi_replay", n * (P * P + 16) * Cc * embeds.element_size(), lambda: check(
-        lib().gar_roi_replay_inplace(dtype_code(embeds.dtype), ptr(embeds), ptr(spans), ptr(rank_pos), rank_pos.shape[1],
+        lib(embeds.dtype).gar_roi_replay_inplace(dtype_code(embeds.dtype), ptr(embeds), ptr(spans), ptr(rank_pos), rank_pos.shape[1],
                                      ptr(jobs), n, n_crop, P, Cc, S, sampling_ratio, int(aligned), stream()),
         "gar_roi_replay_inplace"))
 
@@ -471,13 +471,13 @@ def roi_replay_inplace(embeds, spans, rank_pos, jobs, n_crop, P, Cc, S, sampling
 def embed_assemble(input_ids, slot, E, feats, out, n_feat_rows):
     B, S = input_ids.shape
     _timed("embed_assemble", 2 * out.numel() * out.element_size(), lambda: check(
-        lib().gar_embed_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(feats), ptr(out), B, S,
+        lib(E.dtype).gar_embed_assemble(dtype_code(E.dtype), ptr(input_ids), ptr(slot), ptr(E), ptr(feats), ptr(out), B, S,
                                  E.shape[1], int(n_feat_rows), E.shape[0], stream()), "gar_embed_assemble"))
 
 
 def roi_replay(feats, embeds, spans, crop_index, first_tile, ncw, nch, P, Cc, S, roi, spatial_scale,
                sampling_ratio=2, aligned=True):
-    check(lib().gar_roi_replay(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), crop_index, first_tile, ncw,
+    check(lib(feats.dtype).gar_roi_replay(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), crop_index, first_tile, ncw,
                                nch, P, Cc, S, roi[0], roi[1], roi[2], roi[3], spatial_scale, sampling_ratio,
                                int(aligned), stream()), "gar_roi_replay")
 
@@ -491,7 +491,7 @@ def roi_replay_batched(feats, embeds, spans, jobs, n_crop, tiles_per_sample, P, 
     n = jobs.numel() // 40
     # algorithmic bytes per crop token: P*P*C written + <= 16 map cells * C read
     _timed("roi_replay", n * (P * P + 16) * Cc * feats.element_size(), lambda: check(
-        lib().gar_roi_replay_batched(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), ptr(jobs), n,
+        lib(feats.dtype).gar_roi_replay_batched(dtype_code(feats.dtype), ptr(feats), ptr(embeds), ptr(spans), ptr(jobs), n,
                                      n_crop, tiles_per_sample, P, Cc, S, sampling_ratio, int(aligned), stream()),
         "gar_roi_replay_batched"))
 
@@ -511,25 +511,25 @@ def resize_bicubic_tiles(src_u8, tmp, out, ts, ncw, tile0, xt, yt, mean, std):
     Wout, Hout = xt[2].shape[0], yt[2].shape[0]
     check(lib().gar_resize_bicubic_h(ptr(src_u8), ptr(tmp), H, W, Wout, ptr(xt[0]), ptr(xt[1]), ptr(xt[2]),
                                      xt[2].shape[1], stream()), "gar_resize_bicubic_h")
-    check(lib().gar_resize_bicubic_v_tiles(dtype_code(out.dtype), ptr(tmp), ptr(out), H, Wout, Hout, ts, ncw, tile0,
+    check(lib(out.dtype).gar_resize_bicubic_v_tiles(dtype_code(out.dtype), ptr(tmp), ptr(out), H, Wout, Hout, ts, ncw, tile0,
                                            ptr(yt[0]), ptr(yt[1]), ptr(yt[2]), yt[2].shape[1], mean, std, stream()),
           "gar_resize_bicubic_v_tiles")
 
 
 def resize_nearest_tiles(src_u8, out, ts, ncw, tile0, xi, yi, mean, std):
     H, W, _ = src_u8.shape
-    check(lib().gar_resize_nearest_tiles(dtype_code(out.dtype), ptr(src_u8), ptr(out), H, W, yi.numel(), xi.numel(), ts,
+    check(lib(out.dtype).gar_resize_nearest_tiles(dtype_code(out.dtype), ptr(src_u8), ptr(out), H, W, yi.numel(), xi.numel(), ts,
                                          ncw, tile0, ptr(xi), ptr(yi), mean, std, stream()), "gar_resize_nearest_tiles")
 
 
 def embed_lookup(tokens, E, out):
-    check(lib().gar_embed_lookup(dtype_code(E.dtype), ptr(tokens), ptr(E), ptr(out), tokens.numel(), E.shape[1],
+    check(lib(E.dtype).gar_embed_lookup(dtype_code(E.dtype), ptr(tokens), ptr(E), ptr(out), tokens.numel(), E.shape[1],
                                  E.shape[0], stream()), "gar_embed_lookup")
 
 
 def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace):
     B = logits.shape[0]
-    check(lib().gar_argmax(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
+    check(lib(logits.dtype).gar_argmax(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
                            ptr(step_dev), ptr(cur_tokens), ptr(workspace), stream()), "gar_argmax")
 
 

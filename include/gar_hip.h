@@ -14,6 +14,10 @@
  *     (safe for hipGraph capture).
  *   - `dtype` selects the storage type of activations/weights: GAR_F32 (parity mode, exact-f32 MFMA/VALU math)
  *     or GAR_BF16 (performance mode, bf16 storage, fp32 accumulation). Index tensors are int64 or int32 as stated.
+ *     fp16 (the reference's `--data_type fp16`, demo/gar_with_mask.py:41-45) is the TWIN library libgar_hip_f16.so: the same
+ *     sources compiled with -DGAR_HALF_F16=1 (csrc/common.h), the same entry points and layouts, in which dtype code 1
+ *     means IEEE binary16 storage (conversions round to nearest even, the matrix instructions are the _f16 forms, the
+ *     attention's stored softmax weights stay below 2^15). A host binds one handle per element type (gar_amd/hip.py lib()).
  *   - matrices are row-major; nn.Linear weights keep the PyTorch [out_features, in_features] layout.
  */
 #ifndef GAR_HIP_H

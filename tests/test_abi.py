@@ -25,26 +25,31 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in gar_hip.h but not exported"
     assert set(hip.SIGNATURES) == set(names), set(hip.SIGNATURES) ^ set(names)
     assert lib.gar_abi_version() == hip.ABI_VERSION
+    # the fp16 twin (same sources, -DGAR_HALF_F16=1) exports and binds the same ABI
+    twin = hip.load_library(f16=True)
+    assert twin is not lib and all(hasattr(twin, n) for n in names) and twin.gar_abi_version() == hip.ABI_VERSION
 
 
 def test_code_objects_are_gfx950_only():
-    so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", "libgar_hip.so")
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={so}"],
-                         capture_output=True, text=True)
-    if out.returncode == 0 and out.stdout.strip():
-        targets = [t for t in out.stdout.split() if "amdgcn" in t]
-        assert targets and all("gfx950" in t for t in targets), targets
+    for name in ("libgar_hip.so", "libgar_hip_f16.so"):
+        so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", name)
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={so}"],
+                             capture_output=True, text=True)
+        if out.returncode == 0 and out.stdout.strip():
+            targets = [t for t in out.stdout.split() if "amdgcn" in t]
+            assert targets and all("gfx950" in t for t in targets), targets
 
 
 def test_library_links_no_vendor_math_library():
     """every device computation is this repo's own HIP code: libgar_hip.so depends on the HIP runtime only — no hipBLASLt /
     rocBLAS / MIOpen / composable-kernel library — and the host package calls no torch math on the path (torch.mm and
     friends appear in tools/ as calibration only)."""
-    so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", "libgar_hip.so")
-    out = subprocess.run(["ldd", so], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
-    for lib in ("hipblas", "rocblas", "miopen", "hipblaslt", "rocsparse", "hipdnn"):
-        assert lib not in out.stdout.lower(), (lib, out.stdout)
+    for name in ("libgar_hip.so", "libgar_hip_f16.so"):
+        so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", name)
+        out = subprocess.run(["ldd", so], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        for lib in ("hipblas", "rocblas", "miopen", "hipblaslt", "rocsparse", "hipdnn"):
+            assert lib not in out.stdout.lower(), (lib, out.stdout)
     pkg = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd")
     for f in ("modeling_gar.py", "ops.py"):
         src = open(os.path.join(pkg, f)).read()

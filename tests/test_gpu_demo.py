@@ -63,3 +63,18 @@ def test_demo_clis(tmp_path):
     a = _run("gar_relationship.py", "--image_path", ip, "--mask_paths", *mps, "--question_str", q)
     b = _run("gar_relationship.py", "--image_path", ip, "--mask_paths", *mps, "--question_str", q, "--host_preprocessing")
     assert a == b
+
+
+def test_demo_cli_in_fp16_and_bf16(tmp_path):
+    """--data_type fp16 | bf16 of the reference CLI (demo/gar_with_mask.py:41-45) run end to end (fp16: the twin library);
+    at tiny dimensions both print the caption the fp32 run prints."""
+    from gar_amd.synthetic import synthetic_image, synthetic_mask
+    ip, mp = str(tmp_path / "img.png"), str(tmp_path / "mask.png")
+    synthetic_image(12, 280, 200).save(ip)
+    Image.fromarray(synthetic_mask(12, 280, 200).astype(np.uint8) * 255).save(mp)
+    ref = _run("gar_with_mask.py", "--image_path", ip, "--mask_path", mp)
+    for dt in ("fp16", "bf16"):
+        out = _run("gar_with_mask.py", "--image_path", ip, "--mask_path", mp, "--data_type", dt)
+        assert out, dt
+        if dt == "fp16":
+            assert out == ref          # 3e-3 logit error against margins of the tiny model: the same greedy caption

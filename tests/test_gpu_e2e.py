@@ -9,6 +9,7 @@ from parity_util import F32_LOGIT_TOL, assert_discriminating      # 2e-4 * max|l
 pytestmark = pytest.mark.gpu
 
 BF16_FEAT_TOL = 3e-2      # relative L2 error of image features in bf16 mode vs the f32 oracle
+FP16_FEAT_TOL, FP16_LOGIT_TOL = 4e-3, 8e-3     # the same two bounds for the fp16 twin library (three more mantissa bits)
 BF16_LOGIT_TOL = 4e-2     # ... of first-token logits (two more layers of bf16 rounding on top of the features)
 # sample indices whose oracle sequences are asserted discriminating on the CPU (tests/test_parity_evidence.py)
 TINY_SINGLE, TINY_MULTI, TINY_VIDEO_BASE = 0, 0, 50
@@ -327,6 +328,45 @@ def test_bf16_against_f32_oracle_tiny(tiny):
     assert _rel_l2(feats, inter["image_features"]) < BF16_FEAT_TOL
     # graph replay == eager, bit for bit (same kernels, same order)
     g = m.generate(**s, max_new_tokens=8)
+    assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
+
+
+@pytest.mark.parametrize("dims", ["tiny", "gar_1b_two_layers"])
+def test_fp16_against_f32_oracle(tiny, dims):
+    """--data_type fp16 of the reference CLIs (demo/gar_with_mask.py:41-45): the same kernels with IEEE binary16 as the 16-bit
+    element type (libgar_hip_f16.so, hip.lib(torch.float16)) against the f32 oracle on the fp16-rounded weights — tiny
+    dimensions and GAR-1B dimensions (two ViT blocks + two Llama layers: folded norms, tile GEMM epilogues, head_dim 64
+    attention with the lazy max whose stored softmax weights must stay below fp16's 65504)."""
+    from gar_amd import GARConfig, hip
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    from oracle import gar_oracle as O
+    dt = torch.float16
+    if dims == "tiny":
+        cfg, W, proc = tiny
+        s, n, kw = _sample(cfg, proc, 5, dtype=dt), 8, {}
+    else:
+        cfg = GARConfig.gar_1b(**{"vision.depth": 2, "text.num_hidden_layers": 2})
+        W, proc = synthetic_weights(cfg), GARProcessor.from_config(cfg, max_num_tiles=16)
+        s, n, kw = _sample(cfg, proc, 3, 1024, 1024, dtype=dt), 4, dict(attn_impl="sdpa")
+    Wq = {k: v.to(dt).float() for k, v in W.items()}
+    ref_seq, ref_logits = _oracle(Wq, cfg, s, n, **kw)
+    m = GARModel(cfg, W, dt)
+    out = m.generate(**s, max_new_tokens=n, return_logits=True)
+    assert hip._lib_f16 is not None                                    # the twin library served it
+    lg = out.logits.cpu()
+    assert torch.isfinite(lg).all()
+    assert _rel_l2(lg[:, 0], ref_logits[:, 0]) < FP16_LOGIT_TOL
+    err = float((lg[:, 0] - ref_logits[:, 0]).abs().max())
+    top2 = ref_logits[:, 0].topk(2).values
+    if float(top2[0, 0] - top2[0, 1]) > 2 * err:
+        assert int(out.sequences[0, 0]) == int(ref_seq[0, 0])
+    feats = m.get_image_features(s["pixel_values"], s["global_mask_values"])
+    _, inter = O.build_inputs_embeds(Wq, cfg, s["pixel_values"].float(), s["global_mask_values"].float(),
+                                     s["aspect_ratios"], s["bboxes"], s["input_ids"], return_intermediates=True)
+    assert _rel_l2(feats, inter["image_features"]) < FP16_FEAT_TOL
+    g = m.generate(**s, max_new_tokens=n)                               # graph replay == eager
     assert torch.equal(g.sequences.cpu(), out.sequences.cpu())
 
 

@@ -10,11 +10,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
+# float16: the twin library libgar_hip_f16.so (the same kernels with IEEE binary16 as the 16-bit type, hip.lib(dtype))
+DT = [torch.float32, torch.bfloat16, torch.float16]
+HALF = [torch.bfloat16, torch.float16]
 
 
 def tol(dt):
-    return 2e-5 if dt == torch.float32 else 1.6e-2
+    return {torch.float32: 2e-5, torch.bfloat16: 1.6e-2, torch.float16: 2e-3}[dt]
 
 
 def close(out, ref, dt, scale=None, extra=1.0):
@@ -61,13 +63,13 @@ def test_gemm_plain_and_tails(dev, dt, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(4099, 2048, 192), (8192, 1024, 64), (2049, 4096, 1024), (5000, 1968, 128),
                                    (16640, 2048, 64), (9000, 2048, 128), (33000, 1024, 320)])
-def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
+@pytest.mark.parametrize("dt", HALF)
+def test_gemm_bf16_pingpong_kernel(dev, M, N, K, dt):
     """shapes large enough (>= 128 tiles of 256x256) to take the ping-pong kernel, incl. M / N tails, every epilogue,
     one / two / odd numbers of K tiles and more tiles than CUs (the persistent loop's prefetch wraps into the next
     output tile at every position of the rotated K loop); compared element-wise with an fp64 reference of the same
     bf16 inputs."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     a, w = q(rnd(M, K, seed=50), dt), q(rnd(N, K, seed=51, scale=K ** -0.5), dt)
     A, W_ = a.to(dev, dt), w.to(dev, dt)
     acc = (a.to(dev).double() @ w.to(dev).double().T).cpu()
@@ -101,11 +103,11 @@ def test_gemm_bf16_pingpong_kernel(dev, M, N, K):
         close(o2, F.silu(acc[:, :Fd]) * acc[:, Fd:], dt)
 
 
-def test_gemm_bf16_pingpong_patch_pos_epilogue(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_gemm_bf16_pingpong_patch_pos_epilogue(dev, dt):
     """GAR_EPI_PATCH_POS at a size that takes the ping-pong kernel (row m -> token 1 + m % n of tile m / n of a
     [tiles, n + 1, N] output, + pos-embed row): element-wise against fp64; the cls slots stay untouched."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     T, n, N, K = 16, 1024, 1024, 128
     a, w = q(rnd(T * n, K, seed=90), dt), q(rnd(N, K, seed=91, scale=K ** -0.5), dt)
     pos = q(rnd(n + 1, N, seed=92, scale=0.2), dt)
@@ -176,17 +178,17 @@ def test_norms(dev, dt, D):
     ops.rmsnorm(x.to(dev, dt), w.to(dev, dt), 1e-5, out=y)
     xd = x.double()
     n = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5)
-    if dt == torch.bfloat16:
-        n = n.to(torch.bfloat16).double()
+    if dt in HALF:
+        n = n.to(dt).double()
     close(y, w.double() * n, dt)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("D", [192, 1024])
-def test_norms_two_rows_per_wave_path(dev, D):
+def test_norms_two_rows_per_wave_path(dev, D, dt):
     """bf16, D <= 1024, M >= 4096 takes the two-rows-per-wave kernel: odd M (last wave has one row), in-place, and it
     must agree bit for bit with the one-row kernel (same arithmetic order per row)."""
     from gar_amd import ops
-    dt = torch.bfloat16
     M = 4097
     x = q(rnd(M, D, seed=13, scale=2.0) + 0.3, dt)
     w, b = q(1 + 0.1 * rnd(D, seed=14), dt), q(0.1 * rnd(D, seed=15), dt)
@@ -249,14 +251,14 @@ def test_patch_embed_with_mask_matches_two_convs(dev, dt):
     assert torch.equal(Ah, bref)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("T,npt,with_mask", [(9, 1, True), (8, 0, True), (9, 1, False)])
-def test_patch_embed_gather_matches_two_convs(dev, T, npt, with_mask):
+def test_patch_embed_gather_matches_two_convs(dev, T, npt, with_mask, dt):
     """gar_mask_decode + gar_patch_embed (patches DMA'd from the image tiles into LDS by the tile GEMM, weights in the
     gather's K order) == patch-embed conv + mask conv + pos embed in fp64, and == the im2col + GEMM path within bf16
     rounding; reads that stray out of the tensor with a non-zero weight would show (neighbour images hold 1e4)."""
     from gar_amd import hip, ops
     from oracle import gar_oracle as O
-    dt = torch.bfloat16
     img, patch, D, P = 448, 14, 1024, 5
     g = img // patch
     n = g * g
@@ -304,9 +306,9 @@ def test_patch_embed_gather_matches_two_convs(dev, T, npt, with_mask):
     assert float((d > 0).float().mean()) < 0.05                               # rare last-bit flips only
 
 
-def test_patch_embed_gather_refuses_other_shapes(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_patch_embed_gather_refuses_other_shapes(dev, dt):
     from gar_amd import ops
-    dt = torch.bfloat16
     for T, img, patch, D in [(3, 56, 14, 64), (2, 448, 14, 512), (9, 512, 16, 1024)]:      # grid 4; < 128 tiles; taken
         pix = torch.zeros(T, 3, img, img, dtype=dt, device=dev)
         n = (img // patch) ** 2
@@ -369,7 +371,7 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
     ref = _attn_ref(qq, kk, vv, False, 0).transpose(1, 2).reshape(T * N, D)
     close(out, ref, dt, extra=2.0)
     assert torch.isfinite(out.float()).all()
-    if dt == torch.bfloat16:
+    if dt in HALF:
         # V row-major [T, H, Npad, hd] (what the fused qkv GEMM writes), transposed by the attention's LDS reads
         # (ds_read_b64_tr_b16): same P, same V, same MFMA order -> bit-identical to the Vt form. Pad rows hold large
         # finite values: they meet P = 0 only.
@@ -390,17 +392,17 @@ def test_vit_attention_path(dev, dt, N, npt, hd):
         assert torch.equal(outc2, outc)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("hd", [64, 96, 128])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("profile", ["rising", "spike", "falling", "huge"])
-def test_attention_lazy_max_redo_path(dev, hd, causal, profile):
+def test_attention_lazy_max_redo_path(dev, hd, causal, profile, dt):
     """The bf16 attention exponentiates every tile after the first against the STANDING running max and only checks the
     row sums (attention_bf16.hip, lazy running max); a tile whose scores outgrow that max by more than 2^16 must send the
     wave through the exact path (re-base, redo). Score profiles that force it: keys whose magnitude rises tile by tile,
     one spike tile in the middle, and a fall (the cheap path all the way, with p underflowing to 0); 'huge' jumps by
     more than 2^128 in one tile (exp2 overflows to inf on the lazy pass: the check must still catch it)."""
     from gar_amd import ops
-    dt = torch.bfloat16
     B, H, n = 1, 2, 64 * 9
     g = torch.Generator().manual_seed(77)
     Qf = torch.randn(B, H, n, hd, generator=g)
@@ -543,7 +545,7 @@ def test_llm_prefill_then_decode_attention(dev, dt, S, hd):
             Kf, Vf, o3 = K0.clone(), V0.clone(), torch.full_like(o2, float("nan"))
             took = ops.attention_decode_qkv(x1.view(B, Wd).to(dev, dt), cos.to(dev), sin.to(dev), Kf, Vf, o3, B, Hq, Hkv, hd, Smax,
                                             counters[0:1], scale, nsplit, ws)
-            assert took == (dt == torch.bfloat16)
+            assert took == (dt in HALF)
             if took:
                 assert torch.equal(o3, o2) and torch.equal(Kf, Kc) and torch.equal(Vf, Vc)
         ops.counter_add(counters, 1)
@@ -864,14 +866,14 @@ def test_skinny_gemm_with_fused_rmsnorm(dev, dt, epi):
         close(out, F.silu(n @ gw.double().T) * (n @ uw.double().T), dt, extra=2.0)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("M", [3, 17, 33, 64])
 @pytest.mark.parametrize("N", [768, 8192 + 64])
-def test_skinny_gemm_with_folded_rmsnorm(dev, M, N):
+def test_skinny_gemm_with_folded_rmsnorm(dev, M, N, dt):
     """decode path, gar_gemm_params.norm_folded: W carries the RMSNorm gain, the kernel takes the row sums of squares of the
     activations off the matrix pipe (diagonal of x_tile x_tile^T) and scales the accumulator rows: equals the fp64
     rmsnorm -> linear (-> SwiGLU) of the same bf16 activations; narrow (1-2 weight tiles per block) and wide (4) outputs."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     K = 2048
     x = q(rnd(M, K, seed=140, scale=2.5) + 0.3, dt)
     g = 1 + 0.1 * rnd(K, seed=141)
@@ -889,20 +891,20 @@ def test_skinny_gemm_with_folded_rmsnorm(dev, M, N):
     close(o2, F.silu(y[:, :Fd]) * y[:, Fd:], dt, extra=2.0)
 
 
-def test_gemm_norm_folded_refuses_large_m(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_gemm_norm_folded_refuses_large_m(dev, dt):
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     with pytest.raises(hip.GarError, match="norm_folded"):
         ops.gemm(torch.zeros(65, 128, dtype=dt, device=dev), torch.zeros(64, 128, dtype=dt, device=dev),
                  torch.zeros(65, 64, dtype=dt, device=dev), norm_folded=True, norm_eps=1e-5)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("M", [17, 32, 40, 64])
-def test_skinny_gemm_batched_rows_bf16(dev, M):
+def test_skinny_gemm_batched_rows_bf16(dev, M, dt):
     """decode GEMMs for up to 64 batched sequences: 2 / 4 accumulator row tiles per weight tile, all decode epilogues,
     with and without the fused RMSNorm."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     K, N = 2048, 768
     x = q(rnd(M, K, seed=60, scale=2.0), dt)
     g = q(1 + 0.1 * rnd(K, seed=61), dt)
@@ -954,15 +956,15 @@ def test_skinny_gemm_batched_rows_bf16(dev, M):
     close(o1[0], out[M - 1].float(), dt)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("M", [17, 40, 64])
 @pytest.mark.parametrize("S", [2, 4, 8])
-def test_decode_gemm_split_k_and_fused_reduce(dev, M, S):
+def test_decode_gemm_split_k_and_fused_reduce(dev, M, S, dt):
     """Llama `down` at decode time: K slices of the GEMM written as fp32 partials (gar_gemm split_k) and reduced, together
     with the residual add and the RMSNorm that follows, by gar_splitk_residual_rmsnorm — against fp64, and against the
     unfused pair gemm(EPI_RES) + rmsnorm it replaces (same roundings; only the fp32 summation order of the slices
     differs)."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     K, N = 8192, 2048
     x = q(rnd(M, K, seed=80, scale=1.5), dt)
     w = q(rnd(N, K, seed=81, scale=K ** -0.5), dt)
@@ -992,7 +994,8 @@ def test_decode_gemm_split_k_and_fused_reduce(dev, M, S):
     ulp = (h.float() - h1.float()).abs() / h1.float().abs().clamp_min(1e-3)
     assert float(ulp.max()) <= 2 ** -7 and float((h != h1).float().mean()) < 0.02      # rare 1-ulp flips only
     same = (h == h1).all(-1)
-    assert bool(same.any()) and torch.equal(y[same], y1[same])       # identical rows in -> identical rows out
+    # identical rows in -> identical rows out (fp16's ulp is 8x finer: a row of 2048 without a single flip may not exist)
+    assert (bool(same.any()) or dt == torch.float16) and torch.equal(y[same], y1[same])
     # residual update only (no norm output)
     h2 = h0.to(dev, dt).clone()
     ops.splitk_residual_rmsnorm(partial, h2, None, 1e-5, out=None)
@@ -1025,13 +1028,13 @@ def test_row_rstd_and_stats_finalize(dev):
             assert float((out2.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("epi", ["bias", "gelu", "none_rms", "swiglu_rms"])
-def test_gemm_row_scale_is_the_folded_norm(dev, epi):
+def test_gemm_row_scale_is_the_folded_norm(dev, epi, dt):
     """gar_gemm_params.row_scale: the norm in front of a GEMM folded into it — x goes in un-normalised, the weight is
     W diag(gamma) with centred rows (LayerNorm) or W diag(g) (RMSNorm), the accumulator rows are scaled by rstd[m] and the
     folded bias is added after the scale. Against the fp64 norm -> linear (-> GELU / SwiGLU) of the same bf16 inputs."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     M, K, N = 8300, 1024, 1024
     x = q(rnd(M, K, seed=91) * 1.5 + 0.4, dt)
     W = rnd(N, K, seed=92, scale=K ** -0.5)
@@ -1075,12 +1078,12 @@ def test_gemm_row_scale_is_the_folded_norm(dev, epi):
         ops.gemm(xd[:64], Wf.to(dev, dt), torch.empty(64, N, dtype=dt, device=dev), hip.EPI_NONE, row_scale=rstd)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("epi", ["res", "bsr"])
-def test_gemm_row_stats_of_the_rounded_outputs(dev, epi):
+def test_gemm_row_stats_of_the_rounded_outputs(dev, epi, dt):
     """gar_gemm_params.row_stats: the producer of a folded norm writes (sum, sum of squares) of its bf16-ROUNDED output rows
     per 64-column strip; finalize gives the rstd a LayerNorm / RMSNorm of that output would compute. M and N tails."""
     from gar_amd import hip, ops
-    dt = torch.bfloat16
     M, K, N = 8300, 256, 1000
     a = q(rnd(M, K, seed=96), dt).to(dev, dt)
     w = q(rnd(N, K, seed=97, scale=K ** -0.5), dt).to(dev, dt)
@@ -1113,11 +1116,11 @@ def test_gemm_row_stats_of_the_rounded_outputs(dev, epi):
         assert float((r.cpu().double() - want).abs().max() / want.abs().max()) < 1e-4
 
 
-def test_fused_qkv_rope_with_folded_layernorm(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_fused_qkv_rope_with_folded_layernorm(dev, dt):
     """GAR_EPI_QKV_ROPE fed with the residual stream itself (row_scale = rstd, folded weight / bias): q, k, v equal the fp64
     LayerNorm -> qkv linear -> interleaved RoPE (-> q scale) of the same bf16 x, in attention layout."""
     from gar_amd import ops
-    dt = torch.bfloat16
     T, n, npt, hd, H = 9, 1024, 1, 64, 16
     N, D, Kd = n + npt, 16 * 64, 256
     Npad = (N + 63) // 64 * 64
@@ -1151,10 +1154,11 @@ def test_fused_qkv_rope_with_folded_layernorm(dev):
     close(V1[:, :, :N], vr.permute(0, 2, 1, 3), dt, extra=1.5)
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("hd,Hq,Hkv,B,S", [(64, 8, 2, 3, 3700), (128, 4, 2, 3, 2800), (64, 8, 2, 130, 90)])
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("padded", [False, True])
-def test_fused_llm_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, hd, Hq, Hkv, B, S, fold, padded):
+def test_fused_llm_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, hd, Hq, Hkv, B, S, fold, padded, dt):
     """GAR_EPI_QKV_ROPE_LLM (half-split RoPE, q scale and the KV-cache append in the qkv GEMM's epilogue; W rows in
     llm_qkv_weight_order) against the two-kernel path (GAR_EPI_NONE GEMM -> gar_llm_qkv_post, natural W order) and against an
     fp64 statement of HF's apply_rotary_pos_emb; the fused path rounds to bf16 once instead of twice. With a left-padded
@@ -1162,7 +1166,6 @@ def test_fused_llm_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, hd, Hq, Hkv, B,
     wave's 128-row strip (S = 90: the per-row division path)."""
     from gar_amd import ops
     from oracle import gar_oracle as O
-    dt = torch.bfloat16
     Kd = 256
     Wd = (Hq + 2 * Hkv) * hd
     p0 = 5
@@ -1258,7 +1261,7 @@ def test_llm_qkv_post_and_decode_attention_take_strip_ordered_heads(dev, dt, hd)
         Kf, Vf, o3 = outs[0][1].clone(), outs[0][2].clone(), torch.full_like(o2, float("nan"))
         took = ops.attention_decode_qkv(src, cos, sin, Kf, Vf, o3, B, Hq, Hkv, hd, Smax, counters[0:1], qs, 2, ws, left_pad=lp,
                                         strip_order=strip)
-        assert took == (dt == torch.bfloat16)
+        assert took == (dt in HALF)
         if took:
             assert torch.equal(o3, o2) and torch.equal(Kf, K) and torch.equal(Vf, V)
         res.append((Q1, K, V, o2))
@@ -1315,10 +1318,10 @@ def test_tokens_add(dev):
         assert torch.equal(x.float().cpu(), want)
 
 
-def test_fused_llm_qkv_rope_start_position_from_device_memory(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_fused_llm_qkv_rope_start_position_from_device_memory(dev, dt):
     """qkv_pos_dev overrides qkv_pos0 (graph replay convention of gar_llm_qkv_post)."""
     from gar_amd import ops
-    dt = torch.bfloat16
     hd, Hq, Hkv, B, S, Kd = 64, 8, 2, 3, 3700, 128
     Smax, Spad = 3840, 3712
     pos = torch.arange(Smax, dtype=torch.float32)
@@ -1338,10 +1341,10 @@ def test_fused_llm_qkv_rope_start_position_from_device_memory(dev):
         assert torch.equal(x, y)
 
 
-def test_fused_llm_qkv_rope_refuses_small_problems(dev):
+@pytest.mark.parametrize("dt", HALF)
+def test_fused_llm_qkv_rope_refuses_small_problems(dev, dt):
     """below the tile GEMM's size the fused epilogue does not exist: False (nothing launched), the caller keeps two kernels."""
     from gar_amd import ops
-    dt = torch.bfloat16
     hd, Hq, Hkv, B, S, Kd = 64, 4, 2, 2, 100, 128
     z = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)
     t = torch.zeros(128, hd // 2, device=dev)
@@ -1357,15 +1360,15 @@ def test_abi_errors_are_reported_not_thrown(dev):
         ops.gemm(a, w, torch.zeros(4, 16, device=dev))
 
 
+@pytest.mark.parametrize("dt", HALF)
 @pytest.mark.parametrize("npt,hd,H", [(1, 64, 16), (0, 128, 8), (0, 96, 16)])
 @pytest.mark.parametrize("compact", [True, False])
-def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact):
+def test_fused_qkv_rope_gemm_matches_gemm_plus_qkv_post(dev, npt, hd, H, compact, dt):
     """GAR_EPI_QKV_ROPE (q / k rotated, scaled and laid out by the qkv GEMM's epilogue + gar_vit_v_transpose) against the
     two-kernel path (GAR_EPI_BIAS GEMM -> gar_vit_qkv_post) and against an fp64 statement; the fused path rounds to
     bf16 once instead of twice, so the comparison is within bf16 rounding, not bitwise. Pad rows stay zero."""
     from gar_amd import hip, ops
     # compact: (sin, cos)-pair table + barrier-free per-wave epilogue; not compact: full tables + workgroup-level epilogue
-    dt = torch.bfloat16
     T, n = 4, 1024
     N = n + npt
     D = H * hd

@@ -324,18 +324,14 @@ def test_polygon_rasteriser_known_answers():
     assert c.sum() == 30 * 30 and c[0, 0] == 1
 
 
-def test_fp16_is_parsed_and_refused_with_a_reason():
-    """The reference CLIs offer --data_type fp16 (demo/gar_with_mask.py:44); this path has bf16 / fp32 kernels only:
-    the flag parses, and is refused before anything is loaded — never silently mapped to bf16."""
-    import subprocess
-    import sys
+def test_data_type_choices_are_the_reference_clis():
+    """The reference CLIs offer --data_type fp16 | bf16 | fp32 (demo/gar_with_mask.py:44): each maps to its own arithmetic —
+    fp16 to the twin library (hip.lib(torch.float16)), never silently to bf16 — and the twin binds the same ABI."""
+    from gar_amd import hip
     from gar_amd.bench_loops import DATA_TYPE_CHOICES, resolve_data_type
     assert DATA_TYPE_CHOICES == ["fp16", "bf16", "fp32"]
     assert resolve_data_type("bf16") is torch.bfloat16 and resolve_data_type("fp32") is torch.float32
-    with pytest.raises(SystemExit, match="fp16 is not supported"):
-        resolve_data_type("fp16")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "demo", "gar_with_mask.py"), "--image_path", "x",
-                        "--mask_path", "y", "--data_type", "fp16", "--synthetic_weights"],
-                       capture_output=True, text=True)
-    assert r.returncode != 0 and "fp16 is not supported" in r.stderr
+    assert resolve_data_type("fp16") is torch.float16
+    assert hip.dtype_code(torch.float16) == hip.GAR_BF16 == hip.dtype_code(torch.bfloat16)      # "the library's 16-bit type"
+    a, b = hip.lib(torch.bfloat16), hip.lib(torch.float16)
+    assert a is not b and a is hip.lib(torch.float32) and a.gar_abi_version() == b.gar_abi_version() == hip.ABI_VERSION
