@@ -27,6 +27,8 @@ for p in (ROOT, os.path.join(ROOT, "grasp-any-region_amd")):
 
 import torch  # noqa: E402
 
+HALF_DT = torch.bfloat16      # element type of the timed path; --data-type fp16 switches it (main)
+
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -36,6 +38,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--data-type", choices=["bf16", "fp16"], default="bf16",
+                    help="element type of the timed path: bf16 (BASELINE.json's, the default) or fp16 (the twin library; a "
+                         "secondary line, never the headline)")
     ap.add_argument("--batch", type=int, default=64,
                     help="regions per step per GPU (continuous batching of independent regions)")
     ap.add_argument("--prefill-chunk", type=int, default=0,
@@ -96,12 +101,12 @@ def build_sample(workload, proc, i, device="cpu"):
     from gar_amd.synthetic import RELATIONSHIP_QUESTION, synthetic_disjoint_masks, synthetic_image, synthetic_mask
     if workload == "multi_region":       # 4 disjoint masks, prompt ids 0-3, fixed relationship question
         return MultiRegionDataset(synthetic_image(i), synthetic_disjoint_masks(i, 4), RELATIONSHIP_QUESTION, proc,
-                                  data_dtype=torch.bfloat16, device=device)[0]
+                                  data_dtype=HALF_DT, device=device)[0]
     if workload == "video":              # 8 frames of 1024^2, one mask per frame, one tile + one crop token per frame
         frames = [synthetic_image(8 * i + f) for f in range(8)]
         masks = [synthetic_mask(8 * i + f) for f in range(8)]
-        return VideoRegionCaptionDataset(frames, masks, proc, data_dtype=torch.bfloat16, device=device)[0]
-    return SingleRegionCaptionDataset(synthetic_image(i), synthetic_mask(i), proc, data_dtype=torch.bfloat16,
+        return VideoRegionCaptionDataset(frames, masks, proc, data_dtype=HALF_DT, device=device)[0]
+    return SingleRegionCaptionDataset(synthetic_image(i), synthetic_mask(i), proc, data_dtype=HALF_DT,
                                       device=device)[0]
 
 
@@ -224,9 +229,9 @@ class GpuRuntime:
         W = None
         if rank == 0:
             W = synthetic_weights(cfg, seed=0)
-            model = GARModel(cfg, W, torch.bfloat16, device, prefill_chunk=args.prefill_chunk or None)
+            model = GARModel(cfg, W, HALF_DT, device, prefill_chunk=args.prefill_chunk or None)
         else:
-            model = GARModel.from_shapes(cfg, torch.bfloat16, device)
+            model = GARModel.from_shapes(cfg, HALF_DT, device)
             model.prefill_chunk = args.prefill_chunk or None
         if args.no_patch_gather:
             model.w_patch_gather = None
@@ -242,7 +247,7 @@ class GpuRuntime:
 
     def build_batches(self, args, cfg, rank, world, device):
         from gar_amd.processing import GARProcessor
-        dproc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles).use_gpu_preprocessing(device, torch.bfloat16)
+        dproc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles).use_gpu_preprocessing(device, HALF_DT)
         return build_batches(cfg, dproc, rank, world, args.batch, args.pool, device, args.workload, args.distinct_samples)
 
 
@@ -276,7 +281,9 @@ def load_runtime(spec):
 
 
 def main(argv=None, runtime=None):
+    global HALF_DT
     args = parse(argv)
+    HALF_DT = torch.float16 if args.data_type == "fp16" else torch.bfloat16
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and runtime is None:
         rc = self_launch(args, argv)
         if rc:
@@ -313,11 +320,11 @@ def main(argv=None, runtime=None):
     if args.preprocess == "device":
         from gar_amd.eval_dataset import SingleRegionCaptionDataset
         from gar_amd.synthetic import synthetic_image, synthetic_mask
-        gproc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles).use_gpu_preprocessing(device, torch.bfloat16)
+        gproc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles).use_gpu_preprocessing(device, HALF_DT)
         raw = [(synthetic_image(rank * 1000 + j), synthetic_mask(rank * 1000 + j)) for j in range(4)]
 
         def make_batch(i):
-            sel = [SingleRegionCaptionDataset(*raw[(i * B + k) % len(raw)], gproc, data_dtype=torch.bfloat16,
+            sel = [SingleRegionCaptionDataset(*raw[(i * B + k) % len(raw)], gproc, data_dtype=HALF_DT,
                                               device=device)[0] for k in range(B)]
             return dict(input_ids=torch.cat([s["input_ids"] for s in sel]),
                         pixel_values=torch.cat([s["pixel_values"] for s in sel]),
@@ -501,7 +508,7 @@ def main(argv=None, runtime=None):
     n_crop_rows = int(sum(int((ids0 == t).sum()) for t in (batches[0].get("video_frame_tokens") or cfg.crop_tokens_ids)))
     line = {"metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.data_type, "data": "synthetic",
             "config": {"workload": wl,
                        "regions_per_step_per_gpu": B, "passes": {"vision_tower_tiles": plan_v, "prefill_sequences": plan_l},
                        "decode": "eager launches" if args.no_graph else "one hipGraph replay per token",

@@ -87,7 +87,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         e1.record()
         # M <= 64: the weight-streaming skinny kernels (decode GEMVs, lm_head, the pruned prefill tail) — HBM-bound, priced on
         # bytes; everything larger is the MFMA-bound tile GEMM family
-        kind = ("gemm_skinny" if M <= 64 else "gemm_tile") + ("_bf16" if a.dtype == torch.bfloat16 else "_f32")
+        kind = ("gemm_skinny" if M <= 64 else "gemm_tile") + ("_f32" if a.dtype == torch.float32 else "_bf16")      # "_bf16": the 16-bit kernels (bf16, or fp16 in the twin library)
         prof.append((KERNEL_PHASE + kind, 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), e0, e1))
         return out
     check(lib(a.dtype).gar_gemm(dtype_code(a.dtype), C.byref(p), stream()), "gar_gemm")
