@@ -272,8 +272,9 @@ class GARProcessor:
     aspect_ratio tensor([n_w, n_h]))   (eval_dataset.py:128-139)."""
 
     def __init__(self, tokenizer=None, tile_size: int = 448, max_num_tiles: int = 16, patch_size: int = 14,
-                 pooling_ratio: int = 2):
+                 pooling_ratio: int = 2, chat_template: str = None):
         self.tokenizer = tokenizer or StubTokenizer()
+        self.chat_template = chat_template          # Jinja source from a checkpoint directory (None: the built-in Llama-3 / PLM layout)
         self.image_processor = GARImageProcessor(tile_size, max_num_tiles, "bicubic")
         self.patch_size = patch_size
         self.pooling_ratio = pooling_ratio
@@ -304,11 +305,41 @@ class GARProcessor:
             from .configuration_gar import GARConfig
             cj = os.path.join(path, "config.json")
             cfg = GARConfig.from_json_file(cj) if os.path.exists(cj) else GARConfig.gar_1b()
-        return cls.from_config(cfg, max_num_tiles, tk)
+        proc = cls.from_config(cfg, max_num_tiles, tk)
+        proc.chat_template = cls.read_chat_template(path)
+        return proc
+
+    @staticmethod
+    def read_chat_template(path: str):
+        """The chat template a hub snapshot carries, in transformers' own order of precedence (ProcessorMixin /
+        PreTrainedTokenizerBase): chat_template.jinja, chat_template.json, processor_config.json, tokenizer_config.json.
+        None when the directory has none (the built-in layout is used then)."""
+        import json
+        import os
+        p = os.path.join(path, "chat_template.jinja")
+        if os.path.isfile(p):
+            return open(p, encoding="utf-8").read()
+        for name in ("chat_template.json", "processor_config.json", "tokenizer_config.json"):
+            p = os.path.join(path, name)
+            if os.path.isfile(p):
+                tpl = json.load(open(p, encoding="utf-8")).get("chat_template")
+                if isinstance(tpl, str) and tpl:
+                    return tpl
+        return None
 
     def apply_chat_template(self, messages, add_generation_prompt: bool = True, tokenize: bool = False) -> str:
-        """Llama-3 / PLM chat layout; an image item becomes one ``<|image|>`` ahead of the text."""
+        """The checkpoint's own chat template when its directory had one (rendered by transformers' Jinja environment, as
+        ``processor.apply_chat_template`` of the reference does, evaluation/eval_dataset.py:122); otherwise the Llama-3 /
+        PLM layout it encodes: an image item becomes one ``<|image|>`` ahead of the text."""
         assert not tokenize
+        if self.chat_template:
+            from transformers.utils.chat_template_utils import _compile_jinja_template
+            tk = getattr(self.tokenizer, "tk", None)
+            special = dict(getattr(tk, "special_tokens_map", None) or {})
+            special.setdefault("bos_token", "<|begin_of_text|>")
+            special.setdefault("eos_token", "<|eot_id|>")
+            return _compile_jinja_template(self.chat_template).render(messages=messages,
+                                                                      add_generation_prompt=add_generation_prompt, **special)
         s = "<|begin_of_text|>"
         for m in messages:
             s += f"<|start_header_id|>{m['role']}<|end_header_id|>\n\n"

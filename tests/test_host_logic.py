@@ -335,3 +335,40 @@ def test_data_type_choices_are_the_reference_clis():
     assert hip.dtype_code(torch.float16) == hip.GAR_BF16 == hip.dtype_code(torch.bfloat16)      # "the library's 16-bit type"
     a, b = hip.lib(torch.bfloat16), hip.lib(torch.float16)
     assert a is not b and a is hip.lib(torch.float32) and a.gar_abi_version() == b.gar_abi_version() == hip.ABI_VERSION
+
+
+def test_chat_template_of_a_checkpoint_directory_is_honoured(tmp_path):
+    """(f1) readiness: a hub snapshot carries its chat template (chat_template.jinja / chat_template.json / processor_config.json /
+    tokenizer_config.json, transformers' precedence); GARProcessor.from_pretrained renders THAT through transformers' own Jinja
+    environment. The PLM template gives exactly the built-in layout; another template is honoured, not overridden."""
+    import json
+    from gar_amd import GARConfig
+    from gar_amd.processing import GARProcessor
+    plm = ("{{- bos_token }}{%- for message in messages %}{{- '<|start_header_id|>' + message['role'] + '<|end_header_id|>\\n\\n' }}"
+           "{%- if message['content'] is string %}{{- message['content'] }}{%- else %}{%- for content in message['content'] %}"
+           "{%- if content['type'] == 'image' %}{{- '<|image|>' }}{%- elif content['type'] == 'text' %}{{- content['text'] }}{%- endif %}"
+           "{%- endfor %}{%- endif %}{{- '<|eot_id|>' }}{%- endfor %}"
+           "{%- if add_generation_prompt %}{{- '<|start_header_id|>assistant<|end_header_id|>\\n\\n' }}{%- endif %}")
+    msgs = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Describe <Prompt0> in detail."}]},
+            {"role": "assistant", "content": "A red kite."},
+            {"role": "user", "content": [{"type": "text", "text": "And <Prompt1>?"}]}]
+    cfg = GARConfig.tiny()
+    builtin = GARProcessor.from_config(cfg)
+    d1 = tmp_path / "a"
+    d1.mkdir()
+    (d1 / "chat_template.jinja").write_text(plm)
+    p1 = GARProcessor.from_pretrained(str(d1), cfg)
+    assert p1.chat_template == plm
+    for gen in (True, False):
+        assert p1.apply_chat_template(msgs, add_generation_prompt=gen) == builtin.apply_chat_template(msgs, add_generation_prompt=gen)
+    d2 = tmp_path / "b"
+    d2.mkdir()
+    other = "{{- bos_token }}SYSTEM: be brief." + plm.replace("{{- bos_token }}", "", 1)
+    (d2 / "chat_template.json").write_text(json.dumps({"chat_template": other}))
+    (d2 / "tokenizer_config.json").write_text(json.dumps({"chat_template": "ignored: lower precedence"}))
+    p2 = GARProcessor.from_pretrained(str(d2), cfg)
+    out = p2.apply_chat_template(msgs)
+    assert out.startswith("<|begin_of_text|>SYSTEM: be brief.<|start_header_id|>user") and out.endswith("assistant<|end_header_id|>\n\n")
+    d3 = tmp_path / "c"
+    d3.mkdir()
+    assert GARProcessor.from_pretrained(str(d3), cfg).chat_template is None
