@@ -267,10 +267,18 @@ def self_launch(args, argv):
     argv = list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
-    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(3):
+        # (a free port can be taken between this probe and the launcher's bind: a launch that dies within seconds — at the
+        # rendezvous, before any work — is tried again on another port; a failure after real work is passed through)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+        t0 = time.time()
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0 or time.time() - t0 > 30.0:
+            break
+    return rc
 
 
 def load_runtime(spec):
