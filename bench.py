@@ -258,25 +258,54 @@ def _free_port():
         return s.getsockname()[1]
 
 
+_RENDEZVOUS_MARKERS = ("address already in use", "eaddrinuse", "errno 98", "rendezvousconnectionerror", "rendezvoustimeouterror",
+                       "failed to bind", "the server socket has failed to listen", "connection refused")
+
+
+def _is_rendezvous_failure(stderr_text: str) -> bool:
+    low = stderr_text.lower()
+    return any(m in low for m in _RENDEZVOUS_MARKERS)
+
+
+def _run_tee_stderr(cmd, env):
+    """run cmd; its stdout goes straight through, its stderr is passed through line by line AND its last 200 lines are returned"""
+    import collections
+    import subprocess
+    import threading
+    tail = collections.deque(maxlen=200)
+    p = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+
+    def pump():
+        for line in p.stderr:
+            tail.append(line)
+            sys.stderr.write(line)
+            sys.stderr.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = p.wait()
+    th.join(timeout=5.0)
+    return rc, "".join(tail)
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves — the same command the driver
     documents (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     ...`), one process per GPU — and pass their output and exit code through. The scaling line must not depend on how the caller
     spells the launch (VERDICT r3 #3)."""
-    import subprocess
     argv = list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
     rc = 1
     for attempt in range(3):
-        # (a free port can be taken between this probe and the launcher's bind: a launch that dies within seconds — at the
-        # rendezvous, before any work — is tried again on another port; a failure after real work is passed through)
+        # (a free port can be taken between this probe and the launcher's bind: ONLY a launch whose stderr shows a rendezvous /
+        # address-in-use failure within seconds — before any work — is tried again on another port; every other failure, fast or
+        # slow (bad flag, missing .so, out of memory at init), is passed through at once: ADVICE r4)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
                "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
         print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
         t0 = time.time()
-        rc = subprocess.call(cmd, env=env)
-        if rc == 0 or time.time() - t0 > 30.0:
+        rc, err_tail = _run_tee_stderr(cmd, env)
+        if rc == 0 or time.time() - t0 > 30.0 or not _is_rendezvous_failure(err_tail):
             break
     return rc
 
@@ -454,8 +483,12 @@ def main(argv=None, runtime=None):
         rt.sync()
         td = time.perf_counter() - td
         tcfg = cfg.mllm_config.text_config
-        wbytes = sum(t.numel() * t.element_size() for ly in model.layers for t in ly.values()) + \
-            model.lm_head.numel() * model.lm_head.element_size()
+        # the weights ONE decode step streams: a layer's qkv / o / gate-up / down (the folded forms where the model holds them;
+        # keep_plain_weights=True holds both and must not count twice: ADVICE r4) + lm_head
+        def _streamed(ly):
+            ks = [("qkv_f" if "qkv_f" in ly else "qkv"), "o", ("gu_f" if "gu_f" in ly else "gu"), "down"]
+            return sum(ly[k].numel() * ly[k].element_size() for k in ks)
+        wbytes = sum(_streamed(ly) for ly in model.layers) + model.lm_head.numel() * model.lm_head.element_size()
         kvb = B * (S + args.new_tokens / 2.0) * tcfg.num_hidden_layers * 2 * tcfg.num_key_value_heads * tcfg.head_dim * 2
         decode_loop = {"ms_per_token": td / (args.new_tokens - 1) * 1e3, "steps": args.new_tokens - 1, "sequences": B,
                        "hipgraph": not args.no_graph,
@@ -611,10 +644,10 @@ def main(argv=None, runtime=None):
             hbm_entry("splitk_res_rms_kernel, decode steps (split-K reduce + residual (+ final RMSNorm))", nb, sec, cnt,
                       sec / nsteps_probe * dec_steps / step_s, us_per_decode_step=sec / nsteps_probe * 1e6, note=probe_note)
         tot = sum(a[2] for a in pagg.values())
-        if decode_loop:
-            line["decode_loop"] = decode_loop
         line["decode_step_probe"] = {"eager_us_per_step_sum_of_kernels": tot / nsteps_probe * 1e6, "steps": nsteps_probe,
                                      "kernels_per_step": sum(a[3] for a in pagg.values()) / nsteps_probe}
+    if decode_loop:         # measured whether or not the eager probe ran (--decode-probe-steps 0 must not drop it: ADVICE r4)
+        line["decode_loop"] = decode_loop
     covered = sum(v.get("time_share_of_step", 0.0) for k, v in other.items() if not k.startswith("roi_replay_inplace_kernel alone"))
     line["time_share_covered"] = (roof["time_share_of_step"] if roof else 0.0) + covered
     if not args.no_cpu_baseline and world == 1 and args.workload == "video":

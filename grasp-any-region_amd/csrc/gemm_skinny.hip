@@ -107,8 +107,8 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < (ROWS == 8 ? 1 : 2); ++i)      // ROWS == 8: rows 8..15 of the LDS tile keep whatever they hold (their
-                                                                 // MFMA output rows are never stored; rows do not mix)
+            for (int i = 0; i < (ROWS == 8 ? 1 : 2); ++i)      // ROWS == 8: rows 8..15 of the LDS tile stay zero (cleared once below; their
+                                                                 // MFMA output rows are never stored)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(slot + t * 2048 + i * 1024), 16,
                                                          voffW[i] + (int)((unsigned)(t * 16) * rbW + k0b), 0, 0, SK_W_AUX);
     };
@@ -235,6 +235,14 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
     };
     int ks = ks0;
     if (STAGED) {
+        if (ROWS == 8) {
+            // rows 8..15 of every weight slot are never staged: zero them once so that the MFMAs whose output rows are discarded
+            // consume defined operands (no NaN / Inf bit patterns out of whatever the LDS held). One 1-KiB store per
+            // slot and wave; LDS operations of a wave execute in order, so the fragment reads below see it.
+#pragma unroll
+            for (int d = 0; d < WD; ++d)
+                *reinterpret_cast<u32x4*>(wreg + d * (NT * 2048) + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
         if (ks < ks1) {
             stage_w(ks);
             stage_x(ks);

@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict
 __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
                                                           int64_t* __restrict__ out_tokens, int64_t out_stride,
                                                           const int32_t* __restrict__ step_dev,
-                                                          int64_t* __restrict__ cur_tokens) {
+                                                          int64_t* __restrict__ cur_tokens,
+                                                          const int64_t* __restrict__ eos_ids, int n_eos,
+                                                          int32_t* __restrict__ finished, int32_t* __restrict__ done_count) {
     const int b = blockIdx.x;
     float bv = pv[b * AM_BLOCKS + threadIdx.x];
     int bi = pi[b * AM_BLOCKS + threadIdx.x];
@@ -247,6 +249,17 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
         const int step = step_dev ? step_dev[0] : 0;
         if (out_tokens) out_tokens[(int64_t)b * out_stride + step] = bi;
         if (cur_tokens) cur_tokens[b] = bi;
+        // greedy stopping criterion on the device (HF: EosTokenCriteria over eos_token_id, a list): the FIRST step at which row b
+        // produced an end-of-sequence id is latched in finished[b] (-1 = still running), and done_count counts the latched rows —
+        // the host's "is every row done" poll reads one int instead of scanning the token matrix (entries < 0 of eos_ids never match)
+        if (finished && eos_ids && finished[b] < 0) {
+            bool hit = false;
+            for (int e = 0; e < n_eos; ++e) hit |= (eos_ids[e] == (int64_t)bi);
+            if (hit) {
+                finished[b] = step;
+                if (done_count) atomicAdd(done_count, 1);
+            }
+        }
     }
 }
 
@@ -257,8 +270,9 @@ extern "C" int64_t gar_argmax_workspace(int B, int V) {
 
 extern "C" int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens,
                           int64_t out_stride, const int32_t* step_dev, int64_t* cur_tokens, void* workspace,
-                          gar_stream_t stream) {
+                          const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream) {
     GAR_CHECK_ARG(logits && workspace && B > 0 && V > 0 && (out_tokens || cur_tokens), "argmax: bad args");
+    GAR_CHECK_ARG(n_eos >= 0 && (n_eos == 0 || eos_ids) && (!finished || eos_ids), "argmax: eos_ids / finished");
     float* pv = (float*)workspace;
     int* pi = (int*)(pv + (int64_t)B * AM_BLOCKS);
     hipStream_t s = (hipStream_t)stream;
@@ -267,7 +281,8 @@ extern "C" int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int 
         hipLaunchKernelGGL((argmax_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, V, pv, pi);
     else
         hipLaunchKernelGGL((argmax_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, V, pv, pi);
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, s, pv, pi, out_tokens, out_stride, step_dev, cur_tokens);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, s, pv, pi, out_tokens, out_stride, step_dev, cur_tokens, eos_ids,
+                       n_eos, finished, done_count);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }

@@ -47,6 +47,10 @@ def base_parser(description, default_model, default_cache, default_images):
                          "are grouped) — mathematically the same function, but in bf16 the batch size selects kernels (skinny vs "
                          "tile GEMM, split-K, folded norms), so a caption can differ from the per-item run at near-tied steps; the "
                          "mode a file was produced in is recorded next to it (<cache>.meta.json)")
+    ap.add_argument("--continuous", action="store_true",
+                    help="with --batch_size n > 1: keep n decode rows full instead of running static batches of n — a row whose "
+                         "caption hits EOS is retired and the next queued item is admitted into it inside the running decode loop "
+                         "(gar_amd/continuous.py), so a batch no longer pays for its longest caption in every row")
     ap.add_argument("--synthetic_weights", action="store_true")
     return ap
 
@@ -78,7 +82,8 @@ def write_run_meta(path, args, model):
     """<outputs>.meta.json beside a loop's output file: how the captions were produced (the output file keeps the reference's
     record format). In bf16, batch size and pass sizes select kernels, so two runs of the same items can differ at near-tied
     greedy steps ("Batching and caption-level drift")."""
-    meta = {"batch_size": int(getattr(args, "batch_size", 1) or 1), "data_type": args.data_type,
+    meta = {"batch_size": int(getattr(args, "batch_size", 1) or 1), "continuous": bool(getattr(args, "continuous", False)),
+            "data_type": args.data_type,
             "max_num_tiles": args.max_num_tiles, "max_new_tokens": args.max_new_tokens,
             "synthetic_weights": bool(args.synthetic_weights), "host_preprocessing": bool(args.host_preprocessing),
             "fused_paths": {k: bool(getattr(model, k)) for k in ("FOLD_NORMS", "LLM_QKV_EPILOGUE", "DECODE_GU_NORM_FOLDED",
@@ -171,6 +176,49 @@ class Batcher:
             self._emit(idx, tk.decode(row[:cut], skip_special_tokens=self.skip).strip(), finish)
 
 
+class ContinuousRunner:
+    """The Batcher's interface (``add`` / ``flush`` / ``results``) over :class:`gar_amd.continuous.ContinuousBatcher`: the items
+    are a QUEUE in front of ``batch_size`` decode rows that are refilled as captions end (--continuous)."""
+
+    def __init__(self, model, processor, args, skip_special_tokens):
+        from .continuous import ContinuousBatcher
+        self.processor, self.skip = processor, skip_special_tokens
+        tk = processor.tokenizer
+        self.cb = ContinuousBatcher(model, slots=max(2, int(args.batch_size)), max_new_tokens=args.max_new_tokens,
+                                    eos_token_id=tk.eos_token_id, poll_every=getattr(args, "poll_every", 8))
+        self.pending = {}
+        self.results = []
+        self.items = 0
+
+    def _drain(self):
+        tk = self.processor.tokenizer
+        for ticket, toks in self.cb.pop_finished():
+            idx, finish = self.pending.pop(ticket)
+            text = tk.decode(toks, skip_special_tokens=self.skip).strip()
+            print(text, flush=True)
+            self.results.append((idx, finish(text)))
+
+    def add(self, idx, sample, finish):
+        self.pending[self.cb.submit(sample)] = (idx, finish)
+        self.items += 1
+        self.cb.pump()
+        self._drain()
+
+    def flush(self):
+        self.cb.flush()
+        self._drain()
+        st = self.cb.stats
+        print(f"[continuous] {self.items} items, {self.cb.B} rows: {st['prompt_passes']} prompt passes, {st['decode_steps']} decode "
+              f"steps, row occupancy {st['live_row_steps'] / max(1, st['row_steps']):.2f}, {st['rebases']} re-bases", flush=True)
+        return self.results
+
+
+def make_runner(model, processor, args, skip_special_tokens):
+    if getattr(args, "continuous", False) and int(getattr(args, "batch_size", 1) or 1) > 1:
+        return ContinuousRunner(model, processor, args, skip_special_tokens)
+    return Batcher(model, processor, args, skip_special_tokens)
+
+
 def _gather(local, rank, world):
     """[(index, value)] from every rank -> index-sorted list on rank 0 (None elsewhere)."""
     if world == 1:
@@ -209,7 +257,7 @@ def run_gar_bench(argv=None):
         data = data[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    runner = Batcher(model, processor, args, skip_special_tokens=False)
+    runner = make_runner(model, processor, args, skip_special_tokens=False)
 
     def record(item):
         def finish(text):
@@ -261,7 +309,7 @@ def run_dlc_bench(argv=None):
         order = order[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    runner = Batcher(model, processor, args, skip_special_tokens=True)
+    runner = make_runner(model, processor, args, skip_special_tokens=True)
     for j in dp.shard_indices(len(order), rank, world):
         a = anns[order[j]]
         seg = ast.literal_eval(a["segmentation"]) if isinstance(a["segmentation"], str) else a["segmentation"]
@@ -291,7 +339,7 @@ def _single_region_loop(args, items, get_image, get_mask, make_record):
         items = items[:args.limit]
     prompt_number = model.config.prompt_numbers
     prompt_tokens = [f"<Prompt{i}>" for i in range(prompt_number)] + ["<NO_Prompt>"]
-    runner = Batcher(model, processor, args, skip_special_tokens=True)
+    runner = make_runner(model, processor, args, skip_special_tokens=True)
     for idx in dp.shard_indices(len(items), rank, world):
         item = items[idx]
         image_path, img = get_image(item)
@@ -397,7 +445,7 @@ def run_video_refer(argv=None):
     if args.limit:
         data = data[:args.limit]
     exts = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
-    runner = Batcher(model, processor, args, skip_special_tokens=True)
+    runner = make_runner(model, processor, args, skip_special_tokens=True)
     for idx in dp.shard_indices(len(data), rank, world):
         item = data[idx]
         if "frames" in item:

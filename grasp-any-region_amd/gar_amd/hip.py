@@ -18,7 +18,7 @@ GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
  EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GarError(RuntimeError):
@@ -78,7 +78,7 @@ SIGNATURES = {
     "gar_resize_nearest_tiles": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp], _i),
     "gar_rle_decode": ([C.c_char_p, _i64, _i, _i, _vp], _i64),
     "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
-    "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),
     "gar_counter_add": ([_vp, _i, _i, _vp], _i),
     "gar_input_check": ([_vp, _i, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),

@@ -382,6 +382,7 @@ class GARModel:
         """RCCL broadcast of every prepared weight tensor from rank ``src`` (one-off, bucketed)."""
         from .dp import broadcast_tensors
         broadcast_tensors(self.weight_tensors(), src)
+        self._mask_only_w.clear()       # derived from w_patch / w_patch_gather (mask_patch_embedding): rebuilt from the new weights
 
     def eval(self):
         return self
@@ -535,6 +536,7 @@ class GARModel:
     # the KV-cache states are kept in an LRU of MAX_LLM_STATES entries (their graphs go with them).
     _CAPACITY_FAMILIES = ("vit", "emb", "prefill")
     MAX_LLM_STATES = 2
+    MAX_EOS_IDS = 16          # eos_token_id list entries the device-side stopping criterion holds (longer lists: host scan)
     SPLITK_MAX_ROWS = 64      # csrc/gemm.hip: split_k > 1 and gar_splitk_residual_rmsnorm are built for M <= 64 rows
     DOWN_SPLIT_K = 0          # K slices of the decode `down` GEMM at more than FUSE_NORM_MAX_BATCH rows: 0 = as many as give the
                               # two-weight-tile blocks of the skinny kernel a full grid — (hidden / 32) * slices >= 256: 4 at
@@ -869,6 +871,11 @@ class GARModel:
             # first real row of every sequence (left-padded batch; zeros otherwise): read by the qkv-post and attention
             # kernels of the prefill and of the captured decode step, so one graph serves padded and unpadded requests
             left_pad=self._buf(key, "left_pad", (B,), torch.int32, zero=True),
+            # the greedy loop's stopping criterion, evaluated by the argmax kernel (gar_argmax): the eos ids of the request
+            # (-1 = unused entry), the step at which a row first produced one (-1 = running), the number of finished rows
+            eos_ids=self._buf(key, "eos_ids", (self.MAX_EOS_IDS,), torch.int64),
+            finished=self._buf(key, "finished", (B,), torch.int32),
+            done_count=self._buf(key, "done_count", (1,), torch.int32, zero=True),
             slot=slot,
         )
         return key, st
@@ -990,7 +997,8 @@ class GARModel:
         """the [B*S, (Hq + 2 Hkv) hd] qkv GEMM output of the unfused prefill path (f32 / FOLD_NORMS off): lazily allocated"""
         return self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
 
-    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None):
+    def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None,
+              finished=None):
         """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed). ``normed``: the
         rows after the final norm, when the caller's last launch produced them already (split-K decode path)."""
         cur = st["cur"] if cur is None else cur
@@ -1008,7 +1016,8 @@ class GARModel:
         else:
             ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
             ops.gemm(xn, self.lm_head, logits)
-        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws)
+        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws, eos_ids=st["eos_ids"],
+                   finished=st["finished"] if finished is None else finished, done_count=st["done_count"])
         return logits
 
     def _decode_step(self, st, B: int, Smax: int, out_tokens):
@@ -1202,6 +1211,17 @@ class GARModel:
             st["left_pad"].zero_()
         else:
             st["left_pad"].copy_(left_pad)
+        eos_list = []
+        if eos_token_id is not None:
+            eos_list = [int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
+        # the stopping criterion lives on the device (gar_argmax latches each row's first eos step): fills take their value as a
+        # kernel argument, the id table is one small upload
+        eos_on_device = len(eos_list) <= self.MAX_EOS_IDS
+        st["finished"].fill_(-1)
+        st["done_count"].zero_()
+        st["eos_ids"].fill_(-1)
+        if eos_list and eos_on_device:
+            st["eos_ids"][:len(eos_list)].copy_(torch.tensor(eos_list, dtype=torch.int64).pin_memory(), non_blocking=True)
         V = cfg.mllm_config.text_config.vocab_size
         tiles = 0
         if pixel_values is not None:
@@ -1249,7 +1269,7 @@ class GARModel:
                 embeds = self._buf(("emb", b1 - b0, S), "embeds", (b1 - b0, S, cfg.mllm_config.text_config.hidden_size))
                 ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)
             last = self._prefill(embeds, st, Smax, b0)
-            lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1])
+            lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1], finished=st["finished"][b0:b1])
             if forced_tokens is not None:
                 st["cur"][b0:b1].copy_(forced_tokens[b0:b1, 0])
             if return_logits:
@@ -1265,11 +1285,8 @@ class GARModel:
         c[1:2].fill_(S + 1)
         c[2:3].fill_(1)
         c[3:4].zero_()
-        eos, eos_first = set(), None
-        if eos_token_id is not None:
-            eos_list = [int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
-            eos, eos_first = set(eos_list), (eos_list[0] if eos_list else None)
-        return _PendingGeneration(st=st, skey=skey, B=B, Smax=Smax, V=V, out_tokens=out_tokens, max_new_tokens=max_new_tokens,
+        eos, eos_first = set(eos_list), (eos_list[0] if eos_list else None)
+        return _PendingGeneration(eos_on_device=eos_on_device, st=st, skey=skey, B=B, Smax=Smax, V=V, out_tokens=out_tokens, max_new_tokens=max_new_tokens,
                                   eos=eos, eos_first=eos_first, pad_token_id=pad_token_id, return_logits=return_logits,
                                   all_logits=all_logits, forced_tokens=forced_tokens, use_graph=use_graph, validate=validate,
                                   sync_every=sync_every, input_flags=self._input_flags)
@@ -1308,7 +1325,10 @@ class GARModel:
             if forced_tokens is not None and n_done - 1 < forced_tokens.shape[1]:
                 st["cur"].copy_(forced_tokens[:, n_done - 1])
             if eos and (n_done % sync_every == 0 or n_done == max_new_tokens):
-                fin = self._all_finished(out_tokens, n_done, eos, finished_at)
+                # every row done? ONE int off the device (the argmax kernel latches each row's first eos step and counts the
+                # latched rows); a list longer than MAX_EOS_IDS keeps the host scan of the token matrix
+                fin = int(st["done_count"].item()) >= B if pend.eos_on_device else \
+                    self._all_finished(out_tokens, n_done, eos, finished_at)
                 if not validate:
                     self._raise_on_input_flags()        # the poll above synchronised already
                 if fin:
@@ -1316,16 +1336,17 @@ class GARModel:
         ops.KERNEL_PHASE = ""
         seq = out_tokens[:, :n_done].clone()
         if eos:
-            self._all_finished(out_tokens, n_done, eos, finished_at)
-            host = seq.tolist()
+            if pend.eos_on_device:      # finished[b] = the column of row b's first eos (-1: none within n_done tokens)
+                finished_at = [(c + 1 if 0 <= c < n_done else None) for c in st["finished"].tolist()]
+            else:
+                self._all_finished(out_tokens, n_done, eos, finished_at)
             cut = max((f if f is not None else n_done) for f in finished_at)
-            pad = pad_token_id if pad_token_id is not None else eos_first      # HF: pad defaults to eos_token_id[0]
-            for b in range(B):
-                if finished_at[b] is not None:
-                    for j in range(finished_at[b], cut):
-                        host[b][j] = pad
-                host[b] = host[b][:cut]
-            seq = torch.tensor(host, dtype=torch.int64, device=self.device)
+            if cut < n_done or any(f is not None and f < cut for f in finished_at):
+                pad = pad_token_id if pad_token_id is not None else eos_first      # HF: pad defaults to eos_token_id[0]
+                # rows that finished early hold `pad` behind their eos, as HF's loop writes them; the batch ends at the LAST row's eos
+                cols = torch.arange(cut, device=self.device)[None, :]
+                ends = torch.tensor([(f if f is not None else cut) for f in finished_at], dtype=torch.int64, device=self.device)
+                seq = torch.where(cols < ends[:, None], seq[:, :cut], torch.full_like(seq[:, :cut], int(pad)))
         return GenerateOutput(sequences=seq, logits=torch.stack(all_logits, 1) if return_logits else None,
                               input_flags=None if validate else self._input_flags)
 
@@ -1351,20 +1372,23 @@ class GARModel:
         gkey = (skey, out_tokens.data_ptr(), out_tokens.stride(0))
         g = self._graphs.get(gkey)
         if g is None:
-            saved = st["counters"].clone()
-            saved_cur = st["cur"].clone()
+            # what the warm-up step writes and the loop reads: counters, the current tokens, the stopping-criterion latches
+            names = ("counters", "cur", "finished", "done_count")
+            saved = {n: st[n].clone() for n in names}
+
+            def restore():
+                for n in names:
+                    st[n].copy_(saved[n])
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):                       # warm-up launch outside capture (lazy module load)
                 self._decode_step(st, B, Smax, out_tokens)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize(self.device)
-            st["counters"].copy_(saved)
-            st["cur"].copy_(saved_cur)
+            restore()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
                 logits = self._decode_step(st, B, Smax, out_tokens)
-            st["counters"].copy_(saved)                      # capture does not execute; keep state explicit
-            st["cur"].copy_(saved_cur)
+            restore()                                        # capture does not execute; keep state explicit
             g = self._graphs[gkey] = (g, logits)
         return g

@@ -527,10 +527,17 @@ def embed_lookup(tokens, E, out):
                                  E.shape[0], stream()), "gar_embed_lookup")
 
 
-def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace):
+def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace, eos_ids=None, finished=None, done_count=None):
+    """``eos_ids`` int64 [n] (device, entries < 0 never match), ``finished`` int32 [B] (-1 = running; the kernel latches the step
+    at which a row first produced an eos id), ``done_count`` int32 [1] (number of latched rows): the greedy loop's stopping
+    criterion evaluated on the device (all optional)."""
     B = logits.shape[0]
+    assert eos_ids is None or (eos_ids.dtype == torch.int64 and eos_ids.is_contiguous())
+    assert finished is None or (eos_ids is not None and finished.dtype == torch.int32 and finished.is_contiguous()
+                                and finished.numel() == B)
     check(lib(logits.dtype).gar_argmax(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
-                           ptr(step_dev), ptr(cur_tokens), ptr(workspace), stream()), "gar_argmax")
+                           ptr(step_dev), ptr(cur_tokens), ptr(workspace), ptr(eos_ids),
+                           0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), stream()), "gar_argmax")
 
 
 def argmax_workspace(B, V) -> int:

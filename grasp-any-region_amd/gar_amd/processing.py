@@ -327,19 +327,46 @@ class GARProcessor:
                     return tpl
         return None
 
+    def _compiled_chat_template(self):
+        """The checkpoint's template compiled once. transformers' own (private) compiler when this version has it — it adds
+        the ``raise_exception`` / ``strftime_now`` globals and the JSON filter HF templates may use —, else the same Jinja
+        sandbox built here (no ImportError on a transformers without that symbol)."""
+        cached = getattr(self, "_chat_template_compiled", None)
+        if cached is not None and cached[0] == self.chat_template:
+            return cached[1]
+        try:
+            from transformers.utils.chat_template_utils import _compile_jinja_template
+            tpl = _compile_jinja_template(self.chat_template)
+        except ImportError:
+            import datetime
+            import json
+
+            import jinja2
+            from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+            def raise_exception(message):
+                raise jinja2.exceptions.TemplateError(message)
+
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+            env.filters["tojson"] = lambda x, **kw: json.dumps(x, ensure_ascii=False, **{k: v for k, v in kw.items() if k in ("indent", "sort_keys")})
+            env.globals["raise_exception"] = raise_exception
+            env.globals["strftime_now"] = lambda fmt: datetime.datetime.now().strftime(fmt)
+            tpl = env.from_string(self.chat_template)
+        self._chat_template_compiled = (self.chat_template, tpl)
+        return tpl
+
     def apply_chat_template(self, messages, add_generation_prompt: bool = True, tokenize: bool = False) -> str:
         """The checkpoint's own chat template when its directory had one (rendered by transformers' Jinja environment, as
         ``processor.apply_chat_template`` of the reference does, evaluation/eval_dataset.py:122); otherwise the Llama-3 /
         PLM layout it encodes: an image item becomes one ``<|image|>`` ahead of the text."""
         assert not tokenize
         if self.chat_template:
-            from transformers.utils.chat_template_utils import _compile_jinja_template
             tk = getattr(self.tokenizer, "tk", None)
             special = dict(getattr(tk, "special_tokens_map", None) or {})
             special.setdefault("bos_token", "<|begin_of_text|>")
             special.setdefault("eos_token", "<|eot_id|>")
-            return _compile_jinja_template(self.chat_template).render(messages=messages,
-                                                                      add_generation_prompt=add_generation_prompt, **special)
+            return self._compiled_chat_template().render(messages=messages, add_generation_prompt=add_generation_prompt,
+                                                         **special)
         s = "<|begin_of_text|>"
         for m in messages:
             s += f"<|start_header_id|>{m['role']}<|end_header_id|>\n\n"

@@ -38,7 +38,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 10
+#define GAR_ABI_VERSION 11
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -359,7 +359,13 @@ int64_t gar_rle_decode(const char* counts, int64_t len, int h, int w, uint8_t* m
 int gar_embed_lookup(int dtype, const int64_t* tokens, const void* E, void* out, int B, int C, int64_t vocab,
                      gar_stream_t stream);
 int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
-               const int32_t* step_dev, int64_t* cur_tokens, void* workspace, gar_stream_t stream);
+               const int32_t* step_dev, int64_t* cur_tokens, void* workspace,
+               /* the stopping criterion of HF's greedy loop (eos_token_id may be a list, modeling_gar.py:418-426 forwards the
+                * caller's GenerationConfig; demo/gar_with_mask.py:112-122) evaluated where the token is produced: eos_ids
+                * int64 [n_eos] (device; entries < 0 never match), finished int32 [B] (device; -1 = running, else the step
+                * — column of out_tokens — at which the row FIRST produced an eos id; latched), done_count int32 [1] (device;
+                * number of latched rows). All three may be NULL (n_eos = 0): plain argmax. */
+               const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream);
 int64_t gar_argmax_workspace(int B, int V);
 int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 

@@ -16,6 +16,9 @@ TINY_SINGLE, TINY_MULTI, TINY_VIDEO_BASE = 0, 0, 50
 TINY8B_SINGLE, TINY8B_VIDEO_BASE = 1, 70
 
 
+# bf16 vs f32 at a teacher-forced step of the TINY model (decode-schedule tests): the bound the full-depth tests used before round 5
+TINY_BF16_STEP_REL_L2 = 6e-2
+
 def _sample(cfg, proc, i=0, w=200, h=160, dtype=torch.float32, multi=False):
     from gar_amd.eval_dataset import MultiRegionDataset, SingleRegionCaptionDataset
     from gar_amd.synthetic import synthetic_disjoint_masks, synthetic_image, synthetic_mask
@@ -494,8 +497,8 @@ def test_bf16_decode_above_16_sequences_matches_f32_teacher_forced(tiny):
     assert "down_partial" not in m16u._ws[("decode", 20)]
     for j in range(n):
         # bf16 vs f32 at a teacher-forced step (the first-token tolerance + what later steps add, as in the full-depth test)
-        assert _rel_l2(r16.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
-        assert _rel_l2(u16.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
+        assert _rel_l2(r16.logits[:, j], r32.logits[:, j]) < TINY_BF16_STEP_REL_L2, j
+        assert _rel_l2(u16.logits[:, j], r32.logits[:, j]) < TINY_BF16_STEP_REL_L2, j
         # split vs unsplit differ by the fp32 summation order of `down` only: an order of magnitude closer to each other
         assert _rel_l2(r16.logits[:, j], u16.logits[:, j]) < 5e-3, j
     lg = r16.logits.cpu()
@@ -909,7 +912,10 @@ def test_from_pretrained_hf_style_sharded_checkpoint(tiny, tmp_path, vision_bias
 # tolerances at full depth (23 ViT + 16 Llama layers): f32 rounding differences accumulate through 39 layers, stated
 # separately from the per-layer F32_LOGIT_TOL; measured values are printed by the test (pytest -s) and quoted in DESIGN.md
 FULL_DEPTH_F32_TOL = 2e-4     # measured 8.3e-6
-FULL_DEPTH_BF16_REL_L2 = 6e-2   # measured: first token 4.1e-2, worst of 64 steps 4.8e-2, top-1 agreement 0.906
+FULL_DEPTH_BF16_REL_L2 = 5.3e-2   # measured: first token 4.1e-2, worst of 64 steps 4.8e-2 (B = 64: 4.5e-2), top-1 agreement 0.906
+# floors = what was measured minus two points: a bf16 kernel regression worth 3-4 points must fail
+FULL_DEPTH_BF16_AGREE = 0.885          # measured 0.906 (B = 1, 58 of 64 steps) / 0.940 (B = 64, 64 x 64 steps)
+FULL_DEPTH_BF16_AGREE_WORST_REGION = 0.84   # B = 64: measured 0.875 for the worst of the 64 regions (56 of 64 steps)
 
 
 def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
@@ -958,7 +964,7 @@ def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert max(rel) < FULL_DEPTH_BF16_REL_L2, max(rel)
     for j in (~agree).nonzero().flatten().tolist():
         assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
-    assert rate >= 0.85, rate          # measured 0.906; a regression in a bf16 kernel must not hide below it
+    assert rate >= FULL_DEPTH_BF16_AGREE, rate          # measured 0.906; a regression in a bf16 kernel must not hide below it
     # free-running bf16 through the graph == the same model run eagerly (bit-identical kernels)
     free_g = m16.generate(**sb, max_new_tokens=16)
     free_e = m16.generate(**sb, max_new_tokens=16, use_graph=False)
@@ -1016,7 +1022,9 @@ def test_bench_configuration_bf16_vs_f32_teacher_forced_64_regions():
     assert float(rel.max()) < FULL_DEPTH_BF16_REL_L2, float(rel.max())
     bad = (~agree) & (margins >= 2 * err_row[:, None])
     assert not bool(bad.any()), bad.nonzero().tolist()[:8]
-    assert rate >= 0.85, rate
+    assert rate >= FULL_DEPTH_BF16_AGREE, rate
+    worst_region = float(agree.float().mean(1).min())
+    assert worst_region >= FULL_DEPTH_BF16_AGREE_WORST_REGION, worst_region
     # the same batch through eager launches: the graph replays exactly these kernels
     e16 = m16.generate(**bb, max_new_tokens=8, use_graph=False, forced_tokens=seq32)
     assert torch.equal(e16.sequences, o16.sequences[:, :8])
@@ -1056,8 +1064,9 @@ def test_config0_demo_asset_f32_parity(golden_dir, max_num_tiles, canvas):
 FULL_DEPTH_8B_F32_TOL = 2e-4
 # 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: bound 6e-2, measured 4.8e-2). Measured here: first token 7.1e-2 ... 7.2e-2,
 # worst of 32 steps 7.7e-2 ... 8.0e-2 across builds that differ only in an fp32 summation order (bias as the accumulator
-# start instead of an epilogue add): the same 25 % margin over the measured value as the GAR-1B bound
-FULL_DEPTH_8B_BF16_REL_L2 = 1.0e-1
+# start instead of an epilogue add): bound = the worst measured value + 10 %
+FULL_DEPTH_8B_BF16_REL_L2 = 8.8e-2
+FULL_DEPTH_8B_BF16_AGREE = 0.855      # measured 0.875 (28 of 32 steps)
 
 
 def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
@@ -1106,7 +1115,7 @@ def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert max(rel) < FULL_DEPTH_8B_BF16_REL_L2, max(rel)
     for j in (~agree).nonzero().flatten().tolist():
         assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
-    assert rate >= 0.80, rate          # measured 0.875 (round 3); a regression in the head_dim 96 / 128 kernels must not hide below it
+    assert rate >= FULL_DEPTH_8B_BF16_AGREE, rate          # measured 0.875; a regression in the head_dim 96 / 128 kernels must not hide below it
     free_g = m16.generate(**sb, max_new_tokens=8)
     free_e = m16.generate(**sb, max_new_tokens=8, use_graph=False)
     assert torch.equal(free_g.sequences, free_e.sequences)
@@ -1135,7 +1144,7 @@ def test_bf16_decode_above_64_sequences(tiny):
     lg = out.logits.cpu()
     assert torch.isfinite(lg).all()
     for j in range(n):
-        assert _rel_l2(out.logits[:, j], r32.logits[:, j]) < FULL_DEPTH_BF16_REL_L2, j
+        assert _rel_l2(out.logits[:, j], r32.logits[:, j]) < TINY_BF16_STEP_REL_L2, j
     for r in range(4, 65):
         assert torch.equal(lg[r], lg[r % 4]), r
 

@@ -892,6 +892,50 @@ def test_skinny_gemm_with_folded_rmsnorm(dev, M, N, dt):
 
 
 @pytest.mark.parametrize("dt", HALF)
+@pytest.mark.parametrize("M", [1, 7, 16])
+@pytest.mark.parametrize("N", [8, 24, 2048])
+@pytest.mark.parametrize("form", ["plain", "norm_w", "norm_folded", "bias", "res"])
+def test_skinny_gemm_half_tiles(dev, M, N, form, dt):
+    """M <= 16 rows and N <= 2048 columns take the EIGHT-row half-tile blocks of the skinny GEMM (ROWS = 8: the upper half of a
+    block's MFMA tile is zero, its output rows are never stored — ADVICE r4): every prologue / epilogue the decode step uses on
+    that path against the fp64 reference, with the LDS poisoned first (a launch that fills the CU's LDS with NaN bit patterns:
+    rows 8..15 of a weight slot must not leak into the rows that are stored)."""
+    from gar_amd import hip, ops
+    K = 512
+    x = q(rnd(M, K, seed=240, scale=2.0) + 0.2, dt)
+    w = q(rnd(N, K, seed=241, scale=K ** -0.5), dt)
+    g = q(1 + 0.1 * rnd(K, seed=242), dt)
+    bias = q(rnd(N, seed=243), dt)
+    res = q(rnd(M, N, seed=244), dt)
+    xd, wd = x.double(), w.double()
+    rstd = torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5)
+    # poison: an attention launch that DMA-stages NaN rows through the LDS of every CU
+    nan = torch.full((1, 64, 256, 64), float("nan"), dtype=dt, device=dev)
+    junk = torch.empty(256, 64 * 64, dtype=dt, device=dev)
+    ops.attention(nan, nan, nan, junk, 1, 64, 64, 64, 256, 256, 256, 256, causal=False, v_row_major=True)
+    out = torch.full((M, N), 7.0, dtype=dt, device=dev)
+    xg, wg = x.to(dev, dt), w.to(dev, dt)
+    if form == "plain":
+        ops.gemm(xg, wg, out)
+        ref = xd @ wd.T
+    elif form == "norm_w":
+        ops.gemm(xg, wg, out, norm_w=g.to(dev, dt), norm_eps=1e-5)
+        ref = (xd * rstd * g.double()) @ wd.T
+    elif form == "norm_folded":
+        ops.gemm(xg, wg, out, norm_folded=True, norm_eps=1e-5)
+        ref = (xd @ wd.T) * rstd
+    elif form == "bias":
+        ops.gemm(xg, wg, out, hip.EPI_BIAS, bias=bias.to(dev, dt))
+        ref = xd @ wd.T + bias.double()
+    else:
+        out.copy_(res.to(dev, dt))
+        ops.gemm(xg, wg, out, hip.EPI_RES, residual=out)
+        ref = xd @ wd.T + res.double()
+    assert torch.isfinite(out.float()).all()
+    close(out, ref, dt, extra=2.0)
+
+
+@pytest.mark.parametrize("dt", HALF)
 def test_gemm_norm_folded_refuses_large_m(dev, dt):
     from gar_amd import hip, ops
     with pytest.raises(hip.GarError, match="norm_folded"):

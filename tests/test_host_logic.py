@@ -372,3 +372,30 @@ def test_chat_template_of_a_checkpoint_directory_is_honoured(tmp_path):
     d3 = tmp_path / "c"
     d3.mkdir()
     assert GARProcessor.from_pretrained(str(d3), cfg).chat_template is None
+
+
+def test_chat_template_renders_without_transformers_private_compiler(tmp_path, monkeypatch):
+    """apply_chat_template used a private transformers symbol; on a version without it the template is compiled by the
+    Jinja sandbox built in gar_amd.processing — same rendering, and the compiled template is cached."""
+    import sys
+    import types
+    from gar_amd import GARConfig
+    from gar_amd.processing import GARProcessor
+    cfg = GARConfig.tiny()
+    plm = ("{{- bos_token }}{%- for message in messages %}{{- '<|start_header_id|>' + message['role'] + '<|end_header_id|>\n\n' }}"
+           "{%- for content in message['content'] %}{%- if content['type'] == 'image' %}{{- '<|image|>' }}"
+           "{%- elif content['type'] == 'text' %}{{- content['text'] }}{%- endif %}{%- endfor %}{{- '<|eot_id|>' }}{%- endfor %}"
+           "{%- if add_generation_prompt %}{{- '<|start_header_id|>assistant<|end_header_id|>\n\n' }}{%- endif %}")
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "chat_template.jinja").write_text(plm)
+    msgs = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Describe the masked region."}]}]
+    p = GARProcessor.from_pretrained(str(d), cfg)
+    with_private = p.apply_chat_template(msgs)
+    stub = types.ModuleType("transformers.utils.chat_template_utils")       # a transformers without _compile_jinja_template
+    monkeypatch.setitem(sys.modules, "transformers.utils.chat_template_utils", stub)
+    p2 = GARProcessor.from_pretrained(str(d), cfg)
+    assert p2.apply_chat_template(msgs) == with_private == GARProcessor.from_config(cfg).apply_chat_template(msgs)
+    first = p2._chat_template_compiled[1]
+    p2.apply_chat_template(msgs)
+    assert p2._chat_template_compiled[1] is first

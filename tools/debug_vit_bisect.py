@@ -8,7 +8,7 @@ import torch
 from gar_amd import GARConfig, hip, ops
 from gar_amd.modeling_gar import GARModel, LOG2E
 cfg = GARConfig.gar_1b(**{"vision.depth": 1, "text.num_hidden_layers": 1})
-m = GARModel.from_synthetic(cfg, 0, torch.bfloat16)
+m = GARModel.from_synthetic(cfg, 0, torch.bfloat16, keep_plain_weights=True)   # this tool reads the un-folded n1 / qkv_w / qkv_b
 v = cfg.mllm_config.vision_config
 dev, dt = "cuda:0", torch.bfloat16
 g2 = torch.Generator().manual_seed(2)
