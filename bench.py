@@ -84,6 +84,14 @@ def parse(argv=None):
     ap.add_argument("--prefill-chunk-rows", type=int, default=0, help="A/B: cap on the rows of one prefill pass (GARModel.PREFILL_CHUNK_ROWS)")
     ap.add_argument("--no-prune-last-layer", action="store_true",
                     help="A/B: the last Llama prefill layer over all S rows (the reference's computation) instead of its last row only")
+    ap.add_argument("--eos-mix", action="store_true",
+                    help="secondary line: the reference's REAL calling pattern — generate until EOS under a token cap "
+                         "(demo/gar_with_mask.py:112-122) — on a queue of 3 x --batch regions whose captions have MIXED lengths "
+                         "(synthetic EOS ids picked from the regions' own token streams): static batches of --batch regions per "
+                         "generate() against the continuous batcher (gar_amd/continuous.py: rows retire at EOS, queued regions are "
+                         "admitted into the running decode loop)")
+    ap.add_argument("--eos-mix-tokens", type=int, default=256, help="--eos-mix: max_new_tokens (the reference's callers use 1024)")
+    ap.add_argument("--eos-mix-batches", type=int, default=3, help="--eos-mix: queue length in units of --batch regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args(argv)
@@ -204,6 +212,91 @@ def cpu_baseline(cfg, W, sample, new_tokens, threads):
 
 
 CPU_DECODE_STEPS = 16
+
+
+def pick_synthetic_eos(streams, max_new, target_mean_frac=0.4, max_ids=12):
+    """EOS ids for random-init weights: token ids out of the regions' own free-running streams, most widely shared first, until
+    the captions they cut average ``target_mean_frac * max_new`` tokens — mixed lengths, from a few tokens to the cap."""
+    first = {}
+    for si, s in enumerate(streams):
+        for j, t in enumerate(s):
+            first.setdefault(t, {}).setdefault(si, j + 1)
+    order = sorted(first, key=lambda t: (-len(first[t]), t))
+    lens = [max_new] * len(streams)
+    eos = []
+    for t in order:
+        if len(eos) >= max_ids or sum(lens) / len(lens) <= target_mean_frac * max_new:
+            break
+        new = [min(lens[si], first[t].get(si, max_new)) for si in range(len(streams))]
+        if min(new) < 2 and sum(1 for n in new if n < 2) > len(streams) // 8:
+            continue                    # would end many captions at their first token
+        eos.append(t)
+        lens = new
+    return eos, lens
+
+
+def eos_mix(args, model, make_batch, B, S, tiles, rt):
+    """bench.py --eos-mix: see the flag's help. Both legs run the same kernels on the same regions; a region's
+    caption is cut at its own EOS. Warm-up = one full pass of each leg (graph capture, workspaces)."""
+    from gar_amd.continuous import ContinuousBatcher
+    NM, NB = args.eos_mix_tokens, args.eos_mix_batches
+    batches = [make_batch(i) for i in range(NB)]
+    streams = model.generate(**batches[0], max_new_tokens=NM, eos_token_id=None, validate=False).sequences.cpu().tolist()
+    eos, cal_lens = pick_synthetic_eos(streams, NM)
+
+    def split(batch):
+        out = []
+        for b in range(B):
+            out.append(dict(input_ids=batch["input_ids"][b:b + 1], pixel_values=batch["pixel_values"][b * tiles:(b + 1) * tiles],
+                            global_mask_values=batch["global_mask_values"][b * tiles:(b + 1) * tiles],
+                            bboxes=[batch["bboxes"][b]], aspect_ratios=batch["aspect_ratios"][b:b + 1]))
+        return out
+    regions = [r for bt in batches for r in split(bt)]
+
+    def static_leg():
+        caps, steps = [], 0
+        for bt in batches:
+            rows = model.generate(**bt, max_new_tokens=NM, eos_token_id=eos, validate=False, sync_every=8).sequences.cpu().tolist()
+            steps += len(rows[0]) - 1
+            for row in rows:
+                caps.append(row[:next((j + 1 for j, t in enumerate(row) if t in eos), len(row))])
+        return caps, steps
+
+    def continuous_leg():
+        cb = ContinuousBatcher(model, slots=B, max_new_tokens=NM, eos_token_id=eos, poll_every=8, validate=False)
+        tickets = [cb.submit(r) for r in regions]
+        res = cb.flush()
+        return [res[t] for t in tickets], cb.stats
+
+    def timed(fn):
+        rt.sync()
+        t0 = time.perf_counter()
+        out = fn()
+        rt.sync()
+        return out, time.perf_counter() - t0
+    static_leg()
+    continuous_leg()
+    (caps_s, steps_s), t_s = timed(static_leg)
+    (caps_c, st), t_c = timed(continuous_leg)
+    lens = [len(c) for c in caps_s]
+    same = sum(1 for a, b in zip(caps_s, caps_c) if a == b)
+    n = len(regions)
+    need = sum(x - 1 for x in lens)
+    return {"metric": f"regions/sec until EOS (cap {NM} tokens, mixed caption lengths) {args.model}", "unit": "regions/s",
+            "value": n / t_c, "higher_is_better": True, "n_gpus": 1, "dtype": args.data_type, "data": "synthetic",
+            "config": {"workload": f"queue of {n} regions (1024^2, 1 mask), {B} decode rows, EOS on, max_new_tokens {NM}", "S": S,
+                       "synthetic_eos_ids": len(eos)},
+            "continuous": {"regions_per_s": n / t_c, "seconds": t_c, "decode_steps": st["decode_steps"],
+                           "prompt_passes": st["prompt_passes"], "row_occupancy": st["live_row_steps"] / max(1, st["row_steps"]),
+                           "rebases": st["rebases"]},
+            "static_batches": {"regions_per_s": n / t_s, "seconds": t_s, "decode_steps": steps_s},
+            "speedup_vs_static": t_s / t_c,
+            "caption_lengths": {"min": min(lens), "mean": sum(lens) / n, "max": max(lens),
+                                "decode_tokens_needed": need, "lower_bound_steps": -(-need // B)},
+            "captions_identical_to_static": f"{same}/{n}",
+            "note": "static = generate() per batch of B regions until every row hit EOS (every row pays for the longest caption); "
+                    "continuous = ContinuousBatcher. bf16: the two legs run different batch compositions per step, captions can "
+                    "differ at near-tied steps (INTEGRATION.md)"}
 
 
 class GpuRuntime:
@@ -342,11 +435,10 @@ def main(argv=None, runtime=None):
     rt.sync()
     dp.barrier()
     tb = time.perf_counter()
-    model.broadcast_weights(src=0)                                   # RCCL broadcast over xGMI (no-op at N=1)
+    bcast_n = model.broadcast_weights(src=0)                         # RCCL broadcast over xGMI (no-op at N=1)
     rt.sync()
     bcast_s = dp.max_over_ranks(time.perf_counter() - tb, device)
-    wt = getattr(model, "weight_tensors", None)
-    bcast_bytes = sum(t.numel() * t.element_size() for t in wt()) if wt else None
+    bcast_bytes = model.weight_arena_bytes() if hasattr(model, "weight_arena_bytes") else None
     if args.workload != "single" and args.preprocess == "device":
         raise SystemExit("--preprocess device is wired for --workload single")
     batches, one, n_distinct = rt.build_batches(args, cfg, rank, world, device)
@@ -371,6 +463,11 @@ def main(argv=None, runtime=None):
     else:
         def make_batch(i):
             return batches[i % len(batches)]
+
+    if args.eos_mix:
+        if rank == 0:
+            print(json.dumps(eos_mix(args, model, make_batch, B, S, tiles, rt)), flush=True)
+        return
 
     pool = None
     if args.preprocess == "device":
@@ -575,8 +672,9 @@ def main(argv=None, runtime=None):
             "roofline": roof,
             **dp.describe(),
             "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
-            "weight_broadcast": {"seconds": bcast_s, "bytes": bcast_bytes, "note": "one bucketed broadcast of the prepared weight "
-                                 "tensors from rank 0 before the warm-up (RCCL over xGMI; a no-op at N = 1)"}}
+            "weight_broadcast": {"seconds": bcast_s, "bytes": bcast_bytes, "collectives": bcast_n,
+                                 "note": "ONE in-place broadcast per dtype arena of the prepared weights (bytes = the arena) from rank 0 "
+                                         "before the warm-up (RCCL over xGMI; no collective at N = 1)"}}
     # ---- every other kernel family of the step: achieved / peak / frac and its share of the step -------------------------
     other = line["roofline_other"] = {}
 

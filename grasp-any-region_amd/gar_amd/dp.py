@@ -69,6 +69,19 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
                 off += b.numel()
 
 
+def broadcast_arenas(arenas, src: int = 0) -> int:
+    """The weight exchange of the data-parallel runner: ``arenas`` = {dtype: flat tensor} holding every
+    prepared weight of a replica (gar_amd.weights.pack_arenas) — ONE in-place broadcast per arena from rank ``src``, no staging
+    copy. Returns the number of collectives issued (0 without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    n = 0
+    for dt in sorted(arenas, key=str):          # the same order on every rank
+        dist.broadcast(arenas[dt], src=src)
+        n += 1
+    return n
+
+
 def gather_captions(local_ids: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """[n_local, n_new] int64 from every rank -> list on rank `dst` (None elsewhere)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

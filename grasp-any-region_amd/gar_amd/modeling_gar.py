@@ -330,6 +330,7 @@ class GARModel:
         check_weights(config, weights)
         with torch.cuda.device(self.device):
             self._prepare_weights(weights)
+            self._pack_weights()
         self.mllm = _MllmFacade(self)
         self.mask_patch_embedding = _MaskPatchEmbedding(self)
         self._mask_only_w = {}
@@ -362,27 +363,52 @@ class GARModel:
         W = {k: torch.empty(s, dtype=dtype, device=device) for k, s in weight_shapes(config).items()}
         return cls(config, W, dtype, device)
 
-    def weight_tensors(self) -> List[torch.Tensor]:
-        ts = [self.w_patch, self.pos, *self.norm_pre, *self.pj.values(), self.E, self.final_norm]
+    def _weight_slots(self):
+        """where every prepared weight tensor lives: (container, key, index-in-tuple or None), in a fixed order"""
+        own = self.__dict__
+        slots = [(own, "w_patch", None), (own, "pos", None), (own, "norm_pre", 0), (own, "norm_pre", 1)]
+        slots += [(self.pj, k, None) for k in self.pj]
+        slots += [(own, "E", None), (own, "final_norm", None)]
         if self.cls is not None:
-            ts.append(self.cls)
+            slots.append((own, "cls", None))
         if self.w_patch_gather is not None:
-            ts.append(self.w_patch_gather)
+            slots.append((own, "w_patch_gather", None))
         if self.lm_head is not self.E:
-            ts.append(self.lm_head)
-        for blk in self.vblocks:
-            for v in blk.values():
-                ts.extend(v if isinstance(v, tuple) else [v])
-        for ly in self.layers:
-            ts.extend(ly.values())
-        return ts
+            slots.append((own, "lm_head", None))
+        for d in list(self.vblocks) + list(self.layers):
+            for k, v in d.items():
+                slots += [(d, k, i) for i in range(len(v))] if isinstance(v, tuple) else [(d, k, None)]
+        return slots
+
+    def weight_tensors(self) -> List[torch.Tensor]:
+        return [c[k] if i is None else c[k][i] for c, k, i in self._weight_slots()]
+
+    def _pack_weights(self):
+        """Move every prepared weight into ONE allocation per dtype (``self.arenas``) and re-bind the tensors as views of it: the
+        data-parallel weight exchange is then one in-place RCCL broadcast per arena — no concatenated bucket
+        copies — and a replica's weights are one contiguous range of HBM."""
+        from .weights import pack_arenas
+        tied = self.lm_head is self.E
+        slots = self._weight_slots()
+        self.arenas, views = pack_arenas([c[k] if i is None else c[k][i] for c, k, i in slots])
+        for (c, k, i), v in zip(slots, views):
+            if i is None:
+                c[k] = v
+            else:
+                c[k] = tuple(v if j == i else x for j, x in enumerate(c[k]))
+        if tied:
+            self.lm_head = self.E
 
     @_on_model_device
     def broadcast_weights(self, src: int = 0):
-        """RCCL broadcast of every prepared weight tensor from rank ``src`` (one-off, bucketed)."""
-        from .dp import broadcast_tensors
-        broadcast_tensors(self.weight_tensors(), src)
+        """RCCL broadcast of the prepared weights from rank ``src``: one collective per dtype arena, in place (one-off)."""
+        from .dp import broadcast_arenas
+        n = broadcast_arenas(self.arenas, src)
         self._mask_only_w.clear()       # derived from w_patch / w_patch_gather (mask_patch_embedding): rebuilt from the new weights
+        return n
+
+    def weight_arena_bytes(self) -> int:
+        return sum(a.numel() * a.element_size() for a in self.arenas.values())
 
     def eval(self):
         return self

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import hashlib
 import math
-from typing import Dict, Iterable, Tuple
+from typing import List, Dict, Iterable, Tuple
 
 import torch
 
@@ -270,3 +270,26 @@ def check_weights(cfg, weights: Dict[str, torch.Tensor]) -> None:
     for k, shp in shapes.items():
         if tuple(weights[k].shape) != tuple(shp):
             raise ValueError(f"{k}: expected {shp}, got {tuple(weights[k].shape)}")
+
+
+ARENA_ALIGN_BYTES = 256      # every tensor's offset inside its arena (buffer descriptors / 16-byte vector loads need 16)
+
+
+def pack_arenas(tensors: List[torch.Tensor]) -> Tuple[Dict[torch.dtype, torch.Tensor], List[torch.Tensor]]:
+    """One flat allocation per dtype holding all of ``tensors`` (device and order kept; offsets aligned to ARENA_ALIGN_BYTES),
+    and the list of VIEWS that replace them (same shapes, same values). SURVEY.md section 8e: the data-parallel weight exchange
+    is one message per dtype-contiguous arena — ``dp.broadcast_arenas`` — instead of a concatenated copy per bucket."""
+    offs, sizes = [], {}
+    for t in tensors:
+        al = ARENA_ALIGN_BYTES // t.element_size()
+        o = (sizes.get(t.dtype, 0) + al - 1) // al * al
+        offs.append(o)
+        sizes[t.dtype] = o + t.numel()
+    dev = tensors[0].device if tensors else None
+    arenas = {dt: torch.zeros(n, dtype=dt, device=dev) for dt, n in sizes.items()}
+    views = []
+    for t, o in zip(tensors, offs):
+        v = arenas[t.dtype][o:o + t.numel()].view(t.shape)
+        v.copy_(t)
+        views.append(v)
+    return arenas, views

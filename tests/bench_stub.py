@@ -14,15 +14,20 @@ LOG = {"generate_calls": 0, "syncs": 0}
 class StubModel:
     def __init__(self, rank):
         # rank 0 holds the "weights", the other ranks an uninitialised replica (GARModel.from_shapes)
-        self.w = [torch.full((3000,), 3.0) if rank == 0 else torch.full((3000,), float("nan")),
-                  torch.arange(17, dtype=torch.int64) if rank == 0 else torch.zeros(17, dtype=torch.int64)]
+        from gar_amd.weights import pack_arenas
+        w = [torch.full((3000,), 3.0) if rank == 0 else torch.full((3000,), float("nan")),
+             torch.arange(17, dtype=torch.int64) if rank == 0 else torch.zeros(17, dtype=torch.int64)]
+        self.arenas, self.w = pack_arenas(w)         # like GARModel._pack_weights: one allocation per dtype, the tensors are views
 
     def weight_tensors(self):
         return self.w
 
+    def weight_arena_bytes(self):
+        return sum(a.numel() * a.element_size() for a in self.arenas.values())
+
     def broadcast_weights(self, src=0):
         from gar_amd import dp
-        dp.broadcast_tensors(self.w, src)
+        return dp.broadcast_arenas(self.arenas, src)
 
     def generate(self, input_ids=None, max_new_tokens=64, **kw):
         assert kw.get("validate") is False and kw.get("eos_token_id", 0) is None

@@ -63,7 +63,9 @@ def test_bench_control_flow_world2(tmp_path):
     # the rank proof: what the process group was, every rank's own clock, the broadcast
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and len(d["per_rank_ms_per_step"]) == 2
     assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"]
+    # one collective per dtype arena (float32 + int64), bytes = the arenas (3000 * 4 and 17 * 8: each a single tensor at offset 0)
     assert d["weight_broadcast"]["bytes"] == 3000 * 4 + 17 * 8 and d["weight_broadcast"]["seconds"] >= 0
+    assert d["weight_broadcast"]["collectives"] == 2
     cores = os.cpu_count() or 2
     assert r0["threads"] == r1["threads"] == max(1, cores // 2)    # the ranks share the host cores
 

@@ -33,6 +33,25 @@ def _worker(rank, world, port, out_dir):
     mine = [t.clone() if rank == 0 else torch.zeros_like(t) for t in ref]
     dp.broadcast_tensors(mine, src=0, bucket_bytes=64 * 1024)
     assert all(torch.equal(a, b) for a, b in zip(mine, ref))
+    # ---- the replica's weights as ONE arena per dtype: one in-place collective per arena, bit-equal replicas
+    import torch.distributed as dist
+    from gar_amd.weights import ARENA_ALIGN_BYTES, pack_arenas
+    src_w = [t.clone() if rank == 0 else torch.full_like(t, 7) for t in ref]
+    arenas, views = pack_arenas(src_w)
+    assert set(arenas) == {torch.float32, torch.int64, torch.bfloat16}
+    for v, t in zip(views, src_w):               # views of the arena, aligned, same values
+        a = arenas[v.dtype]
+        off = v.data_ptr() - a.data_ptr()
+        assert 0 <= off < a.numel() * a.element_size() and off % ARENA_ALIGN_BYTES == 0 and torch.equal(v, t)
+    calls = []
+    real = dist.broadcast
+    dist.broadcast = lambda t, src=0, **kw: (calls.append(t.data_ptr()), real(t, src=src, **kw))[1]
+    try:
+        n = dp.broadcast_arenas(arenas, src=0)
+    finally:
+        dist.broadcast = real
+    assert n == len(arenas) == len(calls) and sorted(calls) == sorted(a.data_ptr() for a in arenas.values())
+    assert all(torch.equal(v, t) for v, t in zip(views, ref))
     # ---- region sharding + caption gather
     n_regions, n_new = 7, 5
     idx = dp.shard_indices(n_regions, rank, world)

@@ -147,7 +147,36 @@ def test_generate_eos_latches_on_the_device(tiny):
     assert all(rows[b][:max(lens)] == free[b][:lens[b]] + [pad] * (max(lens) - lens[b]) for b in range(5))
     assert len(rows[0]) == max(lens) or max(lens) == NT
     # a list longer than the device table keeps the host scan: same output
-    many = eos + [400 + i for i in range(m.MAX_EOS_IDS)]
-    assert all(t not in many[len(eos):] for r in free for t in r)
+    seen = {t for r in free for t in r}
+    many = eos + [t for t in range(cfg.mllm_config.text_config.vocab_size) if t not in seen][:m.MAX_EOS_IDS]
+    assert len(many) > m.MAX_EOS_IDS
     out2 = m.generate(**batch, max_new_tokens=NT, eos_token_id=many, generation_config=dict(pad_token_id=pad))
     assert out2.sequences.cpu().tolist() == rows
+
+
+def test_continuous_at_gar1b_dimensions_f32():
+    """GAR-1B's real dimensions (17 tiles of 1025 tokens, S ~ 4.7k, head_dim 64, GQA 32 / 8) with one ViT layer and two Llama
+    layers, f32: ten regions through four decode rows — admissions at cache offsets that are not multiples of a kv tile — give
+    every region the tokens of its own single-region generate()."""
+    from gar_amd import GARConfig
+    from gar_amd.continuous import ContinuousBatcher
+    from gar_amd.modeling_gar import GARModel
+    from gar_amd.processing import GARProcessor
+    from gar_amd.weights import synthetic_weights
+    cfg = GARConfig.gar_1b(**{"vision.depth": 1, "text.num_hidden_layers": 2})
+    W = synthetic_weights(cfg)
+    proc = GARProcessor.from_config(cfg, max_num_tiles=16)
+    m = GARModel(cfg, W, torch.float32)
+    B, NT = 4, 14
+    samples = [_sample(cfg, proc, 400 + i, 1024, 1024) for i in range(10)]
+    assert samples[0]["pixel_values"].shape[0] == 17 and samples[0]["input_ids"].shape[1] > 4600
+    streams = [m.generate(**s, max_new_tokens=NT).sequences[0].cpu().tolist() for s in samples]
+    eos, lens = _pick_eos(streams, 4, NT)
+    exp = _single_runs(m, samples, NT, eos)
+    cb = ContinuousBatcher(m, slots=B, max_new_tokens=NT, eos_token_id=eos, poll_every=3, admit_min=1)
+    tickets = [cb.submit(s) for s in samples]
+    res = cb.flush()
+    print(f"lengths {lens}; stats {cb.stats}")
+    for t, e in zip(tickets, exp):
+        assert res[t] == e, (t, res[t], e)
+    assert cb.stats["prompt_passes"] >= 3 and cb.stats["decode_steps"] < sum(max(lens[i:i + B]) - 1 for i in range(0, 10, B)) + NT
