@@ -19,6 +19,11 @@
 // attention_bf16.hip: DMA-staged bf16 kernel (default for bf16); false -> use the register-staged kernel below
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
+                          const int32_t* kv_start, int kv_prefix, hipStream_t s, int o_rows = 0);
+// attention_v4.hip: the 4-wave persistent kernel (head_dim 64, row-major V, >= 256 query rows): query rows q_row0 .. q_row0 + q_len - 1
+// of sequences of q_total rows; false -> not built for this problem
+bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd, int q_row0,
+                          int q_len, int q_total, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s);
 
 typedef float f32v2 __attribute__((ext_vector_type(2)));
@@ -451,6 +456,22 @@ extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const
         else launch_attn<128>(dtype, Q, K, V, O, B, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, kv_start, s, true);
         GAR_CHECK_LAUNCH();
         return GAR_OK;
+    }
+    if (dtype == GAR_BF16 && hd == 64 && q_len >= 256 && !kv_len_dev) {
+        // v4 (attention_v4.hip) walks 256-row Q blocks. A non-causal sequence whose length is a few rows more than a multiple of
+        // 256 — the ViT tile: 1 cls + 1024 patch tokens — gives those first rows to v2 (one q-block with `head` live rows costs
+        // what a ninth of the tile costs) and whole blocks to v4, instead of a fifth 256-row block with one live row.
+        const int head = (!causal && (q_len % 256) <= 32) ? q_len % 256 : 0;
+        if (gar_attn_bf16_v4_try(Q, K, V, O, B, Hq, Hkv, hd, head, q_len - head, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev,
+                                 kv_start, kv_prefix, s)) {
+            if (head && !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, head, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,
+                                              kv_prefix, s, q_len)) {
+                gar_set_error("attention_vrow: the head rows of a v4 launch were refused by v2");
+                return GAR_ERR_UNSUPPORTED;
+            }
+            GAR_CHECK_LAUNCH();
+            return GAR_OK;
+        }
     }
     if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
         !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,

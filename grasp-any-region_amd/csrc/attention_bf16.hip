@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int Hq, int Hkv, int q_len, int q_pad, int kv_len_arg,
                                                               int kv_stride, const int32_t* __restrict__ kv_len_dev,
-                                                              const int32_t* __restrict__ kv_start, int kv_prefix) {
+                                                              const int32_t* __restrict__ kv_start, int kv_prefix, int o_rows) {
     // head_dim 96 (PE-G/14): K rows are 192 B in HBM; the LDS image keeps the 256-B row pitch of head_dim 128 (a
     // 4-row x 256-B DMA piece per instruction; the 64 bytes past a row's 12 real chunks are filled with a repeat of
     // chunk 11 and never read), so the fragment reads use the conflict-free head_dim-128 swizzle
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
     const int qi = q0 + l31;
     if (qi < q_len) {
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        bf16_t* op = O + ((int64_t)b * q_len + qi) * ((int64_t)Hq * HD) + head * HD;
+        bf16_t* op = O + ((int64_t)b * o_rows + qi) * ((int64_t)Hq * HD) + head * HD;      // o_rows: rows of O per batch item (>= q_len)
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -523,14 +523,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_v2_kernel(const bf16_t* __re
 // vrow: V is row-major [B, Hkv, kv_stride, hd] instead of transposed (head_dim 64 only).
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
-                          const int32_t* kv_start, int kv_prefix, hipStream_t s) {
+                          const int32_t* kv_start, int kv_prefix, hipStream_t s, int o_rows) {
     if ((int64_t)kv_stride * hd * 2 >= (int64_t)1 << 31) return false;
+    if (o_rows <= 0) o_rows = q_len;          // the first q_len query rows of sequences that hold o_rows rows in O (v4 takes the rest)
     dim3 grid(((q_len + 127) / 128) * Hq * B), block(256);
     const int kt = 64 * (hd == 64 ? 128 : 256);
     const int lds = 2 * (kt + (vrow ? kt : hd * 128));
 #define LAUNCH_V2(HD_, C_, V_)                                                                                         \
     hipLaunchKernelGGL((attn_bf16_v2_kernel<HD_, C_, V_>), grid, block, lds, s, (const bf16_t*)Q, (const bf16_t*)K,    \
-                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix)
+                       (const bf16_t*)Vt, (bf16_t*)O, Hq, Hkv, q_len, q_pad, kv_len, kv_stride, kv_len_dev, kv_start, kv_prefix, o_rows)
     if (hd == 64) {
         if (vrow) { if (causal) LAUNCH_V2(64, true, true); else LAUNCH_V2(64, false, true); }
         else { if (causal) LAUNCH_V2(64, true, false); else LAUNCH_V2(64, false, false); }

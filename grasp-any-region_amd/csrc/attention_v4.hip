@@ -62,6 +62,12 @@ __device__ __forceinline__ bf16x8 v4_lds_b128(unsigned addr) {
     return d;
 }
 template <int OFF>
+__device__ __forceinline__ u32x2 v4_lds_b64(unsigned addr) {
+    u32x2 d;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
+    return d;
+}
+template <int OFF>
 __device__ __forceinline__ tr4_t v4_lds_tr(unsigned addr) {
     tr4_t d;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
@@ -77,6 +83,11 @@ __device__ __forceinline__ void v4_wait_lgkm2(tr4_t& x, tr4_t& y) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "i"(N));
 }
 __device__ __forceinline__ void v4_wait_vm(int n) {          // n wave-uniform: at most n VMEM operations outstanding (rounded down)
+    // a TAKEN branch costs a lone wave ~100 cycles of instruction refetch: the steady state (4: the newest tile DMA) falls through
+    if (__builtin_expect(n >= 4 && n < 8, 1)) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        return;
+    }
     if (n >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
     else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -87,16 +98,144 @@ __device__ __forceinline__ void v4_wait_vm(int n) {          // n wave-uniform: 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #define V4_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifdef V4_TIMELINE   /* diagnostic build (tools/attn_v4_timeline.py): shader-clock stamps between the segments of a tile iteration; workgroup 0
+                        writes its per-wave sums over rows 0..3 of O when it is done */
+#define V4_TL(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define V4_TL_ACC { for (int i_ = 0; i_ < 6; ++i_) tl_sum[i_] += tl_t[i_ + 1] - tl_t[i_]; ++tl_n; }
+#else
+#define V4_TL(i)
+#define V4_TL_ACC
+#endif
+// the lane index, opaque to the optimiser: per-lane addresses used once per ITEM are derived from it where they are used — hoisted
+// to the kernel entry they are spilled around the tile loop, and every scratch reload is waited for with vmcnt(0), which drains the
+// DMA ring at each item (the guide's pitfall: recompute per block)
+__device__ __forceinline__ int v4_lane_opaque() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
+
+// Every matrix instruction below opens with `s_nop 1`: hipcc pads no hazards for an asm statement, and under register pressure
+// (the causal instantiation) it parks an operand tuple — the -m start, a P fragment — elsewhere and copies it back with v_mov RIGHT
+// in front of the statement: a VALU write followed at once by the MFMA's read of that register needs two wait states.
+#if GAR_HALF_F16
+#define V4_MFMA_OP "s_nop 1\n\tv_mfma_f32_32x32x16_f16"
+#else
+#define V4_MFMA_OP "s_nop 1\n\tv_mfma_f32_32x32x16_bf16"
+#endif
+// Matrix instructions as inline asm so that the register FILE of every operand is chosen here: with one wave per SIMD the
+// compiler selects the AccVGPR form for every MFMA result, and the scores — which the VALU exponentiates — would come back
+// through 64 v_accvgpr_read per tile. O (touched by MFMAs only), the Q fragments and the K / V fragments (ds_read straight into
+// AccVGPRs) live in the accumulator file; scores, P and the -m start in arch VGPRs.
+// hipcc does not pad hazards around asm: an MFMA result is read by compiler code only behind v4_drain() or a whole phase later.
+__device__ __forceinline__ void v4_mfma_s_first(f32x16& d, const bf16x8& ka, const bf16x8& qb_, const f32x16& c) {
+    asm volatile(V4_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(ka), "a"(qb_), "v"(c));
+}
+__device__ __forceinline__ void v4_mfma_s_acc(f32x16& d, const bf16x8& ka, const bf16x8& qb_) {
+    asm volatile(V4_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(ka), "a"(qb_));
+}
+__device__ __forceinline__ void v4_mfma_o_acc(f32x16& d, const bf16x8& va, const u32x4& pb) {
+    asm volatile(V4_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(va), "v"(pb));
+}
+__device__ __forceinline__ void v4_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+template <int OFF>
+__device__ __forceinline__ bf16x8 v4_lds_b128a(unsigned addr) {          // into AccVGPRs
+    bf16x8 d;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "i"(OFF));
+    return d;
+}
+template <int OFF>
+__device__ __forceinline__ tr4_t v4_lds_tra(unsigned addr) {
+    tr4_t d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "i"(OFF));
+    return d;
+}
+template <int N>
+__device__ __forceinline__ void v4_wait_lgkm_a(bf16x8& x) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(x) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void v4_wait_lgkm_a2(tr4_t& x, tr4_t& y) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+a"(x), "+a"(y) : "i"(N));
+}
+
+// K / V fragments live in an asm-owned window of the accumulator file — a[192:223] = the eight K fragments of a tile (kd-major,
+// kv block minor), a[224:255] = its eight V fragments ((kv block, 16-kv step)-major, d block minor; each two transposing 64-bit
+// reads) — named literally in the asm strings and declared clobbered by every statement that writes them, so the compiler keeps
+// nothing there: the two halves of a V fragment land in ONE 128-bit tuple (built from two asm outputs the compiler copies them
+// together: 4 v_accvgpr_mov per fragment), and a fragment read one phase — or one loop iteration — ahead of its MFMA needs no
+// compiler-visible live range across the barrier.
+#define V4_KF0 192
+#define V4_VF0 224
+#define V4_FR_CLOBBER "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <int F, int OFF>
+__device__ __forceinline__ void v4_kfrag_read(unsigned addr) {          // K fragment F <- LDS
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%3" ::"v"(addr), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(OFF)
+                 : V4_FR_CLOBBER);
+}
+template <int F, int HALF, int OFF>
+__device__ __forceinline__ void v4_vfrag_read(unsigned addr) {          // half HALF (kv rows +0..3 / +4..7 of the step) of V fragment F
+    asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%3" ::"v"(addr), "i"(V4_VF0 + 4 * F + 2 * HALF), "i"(V4_VF0 + 4 * F + 2 * HALF + 1),
+                 "i"(OFF)
+                 : V4_FR_CLOBBER);
+}
+template <int N>
+__device__ __forceinline__ void v4_wait_lgkm_n() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : V4_FR_CLOBBER);
+}
+// O (a[0:63]: q-block qb, d block db at 32 qb + 16 db) and the Q fragments (a[64:95]: q-block qb, k-step kd at 64 + 16 qb + 4 kd) are
+// asm-owned too: as "+a" operands the compiler kept O in arch VGPRs and copied it into the accumulator file around every asm
+// block (70 v_accvgpr moves per phase). Compiler code reaches O only through v4_o_read / v4_o_write (item entry, re-base, epilogue).
+#define V4_O0 0
+#define V4_QF0 64
+#define V4_O_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+#define V4_QF_CLOBBER "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+// S^T (arch VGPRs) = K fragment F x Q fragment (q-block QB, k-step F >> 1) (+ C)
+template <int QB, int F>
+__device__ __forceinline__ void v4_mfma_qk_first(f32x16& d, const f32x16& c) {
+    asm volatile(V4_MFMA_OP " %0, a[%c2:%c3], a[%c4:%c5], %1"
+                 : "=&v"(d)
+                 : "v"(c), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)),
+                   "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3));
+}
+template <int QB, int F>
+__device__ __forceinline__ void v4_mfma_qk_acc(f32x16& d) {
+    asm volatile(V4_MFMA_OP " %0, a[%c1:%c2], a[%c3:%c4], %0"
+                 : "+v"(d)
+                 : "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3));
+}
+// O^T (q-block QB, d block F & 1) += V fragment F x P
+template <int QB, int F>
+__device__ __forceinline__ void v4_mfma_pv(const u32x4& pb) {
+    asm volatile(V4_MFMA_OP " a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(pb), "i"(V4_O0 + 32 * QB + 16 * (F & 1)),
+                 "i"(V4_O0 + 32 * QB + 16 * (F & 1) + 15), "i"(V4_VF0 + 4 * F), "i"(V4_VF0 + 4 * F + 3)
+                 : V4_O_CLOBBER);
+}
+template <int R>
+__device__ __forceinline__ float v4_o_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(V4_O0 + R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ void v4_o_write(float x) {
+    asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(x), "i"(V4_O0 + R) : V4_O_CLOBBER);
+}
+template <int I, int OFF>
+__device__ __forceinline__ void v4_qfrag_read(unsigned addr) {          // Q fragment I (= 4 qb + kd) <- LDS
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%3" ::"v"(addr), "i"(V4_QF0 + 4 * I), "i"(V4_QF0 + 4 * I + 3), "i"(OFF) : V4_QF_CLOBBER);
+}
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bf16_v4_kernel(const v4_args a) {
+#if defined(__HIP_DEVICE_COMPILE__)      // gfx950 inline asm (AccVGPR constraints): the host pass only needs the launch stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int PFX = CAUSAL ? 0 : a.kv_prefix;
-    const int kv_len = (a.kv_len_dev ? a.kv_len_dev[0] : a.kv_len) - PFX;
+    const int kv_len = (a.kv_len_dev ? ((const __attribute__((address_space(4))) int32_t*)a.kv_len_dev)[0] : a.kv_len) - PFX;
     const int coff = kv_len - a.q_total;                 // causal: kv <= q + coff
     const int q_end = a.q_row0 + a.q_len;
     const int G = gridDim.x;
@@ -108,16 +247,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // causal = (Q block from the LAST one down: heavy items first, (b, head)) — the heads of a GQA group are neighbours.
     // Workgroup L runs on XCD L % 8 (round-robin dispatch): in step k it takes item k G + (L % 8) (G / 8) + L / 8, so every XCD
     // works on G / 8 CONSECUTIVE items at a time and re-reads shared slabs from its own L2.
-    struct Item {
-        int valid, b, head, qb, t_lo, ntiles, kv_lo;
-        __amdgpu_buffer_rsrc_t rsK, rsV, rsQ;
-    };
-    auto decode = [&](int k, Item& I) __attribute__((always_inline)) {
+    auto decode = [&](int k, int& b, int& head, int& qb) __attribute__((always_inline)) -> bool {
         const int L = blockIdx.x;
         const int it = (G & 7) == 0 ? k * G + (L & 7) * (G >> 3) + (L >> 3) : k * G + L;
-        I.valid = it < n_items;
-        const int itc = I.valid ? it : 0;
-        int b, head, qb;
+        const bool valid = it < n_items;
+        const int itc = valid ? it : 0;
         if (CAUSAL) {
             const int per = a.B * a.Hq;
             qb = a.nqb - 1 - itc / per;
@@ -130,20 +264,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             b = bh / a.Hq;
             head = bh % a.Hq;
         }
-        I.b = b; I.head = head; I.qb = qb;
-        const int kvh = head / gsz;
-        const int kv_lo = a.kv_start ? max(min(a.kv_start[b], kv_len - 1), 0) : 0;
-        I.kv_lo = kv_lo;
-        I.t_lo = kv_lo >> 6;
+        return valid;
+    };
+    auto kv_lo_of = [&](int b) __attribute__((always_inline)) -> int {
+        // through the constant address space: a scalar load (a vector load here would be waited for with vmcnt(0) and drain the DMA ring)
+        return a.kv_start ? max(min(((const __attribute__((address_space(4))) int32_t*)a.kv_start)[b], kv_len - 1), 0) : 0;
+    };
+    auto ntiles_of = [&](int qb, int kv_lo) __attribute__((always_inline)) -> int {
         int kv_end = kv_len;
         if (CAUSAL) kv_end = min(kv_len, max(min(a.q_row0 + qb * 256 + 255, q_end - 1) + coff, kv_lo) + 1);
-        I.ntiles = (kv_end + 63) >> 6;
-        const bf16_t* Kp = a.K + ((int64_t)b * a.Hkv + kvh) * (int64_t)a.kv_stride * 64;
-        const bf16_t* Vp = a.V + ((int64_t)b * a.Hkv + kvh) * (int64_t)a.kv_stride * 64;
-        const bf16_t* Qp = a.Q + ((int64_t)b * a.Hq + head) * (int64_t)a.q_pad * 64;
-        I.rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)slab, 0x00020000);
-        I.rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)slab, 0x00020000);
-        I.rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, a.q_pad * 128, 0x00020000);
+        return (kv_end + 63) >> 6;
+    };
+    auto slab_rsrc = [&](const bf16_t* base, int b, int head) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
+        const bf16_t* p = base + ((int64_t)b * a.Hkv + head / gsz) * (int64_t)a.kv_stride * 64;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)slab, 0x00020000);
     };
 
     // ---- LDS-DMA: a 64-row tile = 8 pieces of 8 rows x 128 B (1 KiB, lane-linear in LDS); wave w brings pieces w and 4 + w of K
@@ -152,30 +286,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int drow = wave * 8 + (lane >> 3);
     const int voffK = drow * 128 + (((lane & 7) ^ ((drow >> 1) & 7)) << 4);
     const int voffV = drow * 128 + (((lane & 7) ^ (((drow >> 1) & 1) << 2)) << 4);
-    auto issue_tile = [&](const Item& I, int t, int stage) __attribute__((always_inline)) {
-        char* ks = smem + stage * V4_STAGE;
-        const int base = (t * 64 + PFX) * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rsK, LDS_AS(ks + (i * 4 + wave) * 1024), 16, voffK + base + i * 4096, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rsV, LDS_AS(ks + 8192 + (i * 4 + wave) * 1024), 16, voffV + base + i * 4096, 0, 0,
-                                                     0);
+    // DMA cursor: tile d_t of the kd-th item of this workgroup
+    int kdi = 0, d_t, d_nt;
+    bool d_valid;
+    __amdgpu_buffer_rsrc_t d_rsK, d_rsV;
+    auto dma_enter = [&](int k) __attribute__((always_inline)) {
+        int b, head, qb;
+        (void)decode(k, b, head, qb);         // past the last item: item 0 again — the ring keeps its cadence (no branch in the tile
+        d_valid = true;                       // loop, a constant vmcnt), the extra tiles are never read
+        const int lo = kv_lo_of(b);
+        d_t = lo >> 6;
+        d_nt = ntiles_of(qb, lo);
+        d_rsK = slab_rsrc(a.K, b, head);
+        d_rsV = slab_rsrc(a.V, b, head);
     };
-    // the wave's own 64 Q rows of item I (row-major image, no swizzle: read once per item) + the prefix key / value row
+    auto dma_advance = [&]() __attribute__((always_inline)) {
+        if (++d_t >= d_nt) dma_enter(++kdi);
+    };
+    auto dma_piece = [&](auto ic, int stage) __attribute__((always_inline)) {        // piece i of the cursor's tile: K K V V
+        constexpr int i = decltype(ic)::value;
+#ifdef V4_KO_DMA
+        return;
+#endif
+        char* ks = smem + stage * V4_STAGE;
+        const int base = (d_t * 64 + PFX) * 128;
+        if (i < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsK, LDS_AS(ks + ((i & 1) * 4 + wave) * 1024), 16, voffK + base + (i & 1) * 4096, 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsV, LDS_AS(ks + 8192 + ((i & 1) * 4 + wave) * 1024), 16,
+                                                     voffV + base + (i & 1) * 4096, 0, 0, 0);
+    };
+    auto dma_tile = [&](int stage) __attribute__((always_inline)) {
+        v4_for<0, 4>([&](auto ic) __attribute__((always_inline)) { dma_piece(ic, stage); });
+    };
+    // the wave's own 64 Q rows of an item (row-major image, no swizzle: read once per item) + the prefix key / value row
     char* const qbuf = smem + V4_QBUF + wave * V4_QW;
-    char* const obuf = smem + V4_OBUF + wave * 8192;
+    const unsigned qbuf_a = lds0 + V4_QBUF + wave * V4_QW;
     const int voffQ = (lane >> 3) * 128 + ((lane & 7) << 4);
     const int QOPS = 8 + (PFX ? 2 : 0);
-    auto issue_q = [&](const Item& I) __attribute__((always_inline)) {
-        const int row0 = a.q_row0 + I.qb * 256 + wave * 64;
+    auto issue_q = [&](int k) __attribute__((always_inline)) {
+#ifdef V4_KO_Q
+        if (k > 0) return;
+#endif
+        int b, head, qb;
+        (void)decode(k, b, head, qb);
+        const bf16_t* Qp = a.Q + ((int64_t)b * a.Hq + head) * (int64_t)a.q_pad * 64;
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)Qp, 0, a.q_pad * 128, 0x00020000);
+        const int row0 = a.q_row0 + qb * 256 + wave * 64;
 #pragma unroll
         for (int p = 0; p < 8; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rsQ, LDS_AS(qbuf + p * 1024), 16, voffQ + (row0 + p * 8) * 128, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, LDS_AS(qbuf + p * 1024), 16, voffQ + (row0 + p * 8) * 128, 0, 0, 0);
         if (PFX) {          // row 0 of the slab, 8 chunks (replicated over the 8 row slots of the piece)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rsK, LDS_AS(qbuf + 8192), 16, (lane & 7) << 4, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rsV, LDS_AS(qbuf + 9216), 16, (lane & 7) << 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(slab_rsrc(a.K, b, head), LDS_AS(qbuf + 8192), 16, (lane & 7) << 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(slab_rsrc(a.V, b, head), LDS_AS(qbuf + 9216), 16, (lane & 7) << 4, 0, 0, 0);
         }
     };
 
@@ -196,74 +359,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         vaddr0[1] = lds0 + 8192 + (vtr ^ 64);
     }
 
-    // ---- wave state of the current item
-    f32x16 o[2][2];                  // [q-block][d-block]
-    f32x16 negm[2];                  // -m of the q-block's row (16 equal registers: the C operand of the first QK^T MFMA)
-    f32x16 s[2][2][2];               // [parity][q-block][kv block]: scores of the tile being exponentiated / of the next one
-    u32x4 pf[2][2][2][2];            // [parity][q-block][kv block][16-kv step]: P as PV B operands
-    bf16x8 qf[2][4];
+    // ---- wave state of the current item. ONE set of scores and ONE set of P: the two q-blocks run half an iteration apart
+    //   phase A(j): MFMA { S^T(j, qb1) = K(j) Q1^T ;  O1^T += V^T(j-1) P1(j-1) }   |  VALU softmax(j, qb0)   | LDS: K(j+1), V(j) fragments
+    //   phase B(j): MFMA { S^T(j+1, qb0) = K(j+1) Q0^T ;  O0^T += V^T(j) P0(j) }   |  VALU softmax(j, qb1)   | the tile DMA
+    // so every score / P register is consumed before the matrix pipe rewrites it, a q-block's O is complete up to the
+    // previous tile whenever its running max may have to be re-based, and the K / V fragments of a tile — read ONCE into the
+    // AccVGPR window, each slot refilled right behind its last MFMA of phase A — serve both q-blocks.
+    f32x16 negm[2];                  // -m of the q-block's row: the C operand of the first QK^T MFMA
+    f32x16 s[2][2];                  // [q-block][kv block]
+    u32x4 pf[2][2][2];               // [q-block][kv block][16-kv step]: P as PV B operands
     float m_run[2], l_run[2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const auto Q0 = std::integral_constant<int, 0>{};
+    const auto Q1 = std::integral_constant<int, 1>{};
 
-    // QK^T of the tile in `stage` into s[P]: un-overlapped form (first tile of an item, around masked tiles)
-    auto qk_plain = [&](auto pc, int stage) __attribute__((always_inline)) {
-        constexpr int P = decltype(pc)::value;
-        unsigned ka[4];
-#pragma unroll
-        for (int kd = 0; kd < 4; ++kd) ka[kd] = kaddr0[kd] + stage * V4_STAGE;
-        bf16x8 kf[2][4];
-        v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-            constexpr int f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
-            kf[kb][kd] = v4_lds_b128<kb * 4096>(ka[kd]);
-        });
-        v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-            constexpr int f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
-            v4_wait_lgkm<7 - f>(kf[kb][kd]);
-            s[P][0][kb] = MFMA_32x32x16(kf[kb][kd], qf[0][kd], kd == 0 ? negm[0] : s[P][0][kb]);
-            s[P][1][kb] = MFMA_32x32x16(kf[kb][kd], qf[1][kd], kd == 0 ? negm[1] : s[P][1][kb]);
-        });
+    // fragment f of a tile: K (kd = f >> 1, kv block f & 1); V ((kv block, 16-kv step) = f >> 1, d block f & 1)
+    auto k_read = [&](auto fc, const unsigned (&ka)[4]) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value;
+#ifndef V4_KO_LDS
+        v4_kfrag_read<f, (f & 1) * 4096>(ka[f >> 1]);
+#endif
     };
-    // O^T += V^T P of the tile in `stage` with pf[P]
-    auto pv_plain = [&](auto pc, int stage) __attribute__((always_inline)) {
-        constexpr int P = decltype(pc)::value;
-        unsigned va[2] = {vaddr0[0] + (unsigned)(stage * V4_STAGE), vaddr0[1] + (unsigned)(stage * V4_STAGE)};
-        tr4_t lo[8], hi[8];
-        v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-            constexpr int f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
-            lo[f] = v4_lds_tr<(kb * 32 + tt * 16) * 128>(va[db]);
-            hi[f] = v4_lds_tr<(kb * 32 + tt * 16 + 4) * 128>(va[db]);
-        });
-        v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-            constexpr int f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
-            v4_wait_lgkm2<14 - 2 * f>(lo[f], hi[f]);
-            const bf16x8 vf = {lo[f][0], lo[f][1], lo[f][2], lo[f][3], hi[f][0], hi[f][1], hi[f][2], hi[f][3]};
-            o[0][db] = MFMA_32x32x16(vf, __builtin_bit_cast(bf16x8, pf[P][0][kb][tt]), o[0][db]);
-            o[1][db] = MFMA_32x32x16(vf, __builtin_bit_cast(bf16x8, pf[P][1][kb][tt]), o[1][db]);
-        });
+    auto v_read = [&](auto fc, const unsigned (&va)[2]) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
+#ifndef V4_KO_LDS
+        v4_vfrag_read<f, 0, (kb * 32 + tt * 16) * 128>(va[db]);
+        v4_vfrag_read<f, 1, (kb * 32 + tt * 16 + 4) * 128>(va[db]);
+#endif
     };
-    // p = exp2(s) (s carries -m), row sum, bf16 pack of q-block qb of s[P] -> pf[P][qb]; returns this lane's partial row sum
-    auto exp_pack = [&](auto pc, auto qc) __attribute__((always_inline)) -> float {
-        constexpr int P = decltype(pc)::value, qb = decltype(qc)::value;
+    auto qk_mfma = [&](auto qc, auto fc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value, f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
+#ifndef V4_KO_MFMA
+        if constexpr (kd == 0) v4_mfma_qk_first<qb, f>(s[qb][kb], negm[qb]);
+        else v4_mfma_qk_acc<qb, f>(s[qb][kb]);
+#endif
+    };
+    auto pv_mfma = [&](auto qc, auto fc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value, f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
+#ifndef V4_KO_MFMA
+        v4_mfma_pv<qb, f>(pf[qb][kb][tt]);
+#endif
+    };
+    // p = exp2(s) (s carries -m), row sum, bf16 pack of q-block qb -> pf[qb]; returns this lane's partial row sum
+    auto exp_pack = [&](auto qc) __attribute__((always_inline)) -> float {
+        constexpr int qb = decltype(qc)::value;
         float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[P][qb][kb][r]);
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { ps0 += p[r]; ps1 += p[r + 1]; }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
-                pf[P][qb][kb][tt] = u32x4{pack_bf2(p[tt * 8 + 0], p[tt * 8 + 1]), pack_bf2(p[tt * 8 + 2], p[tt * 8 + 3]),
-                                          pack_bf2(p[tt * 8 + 4], p[tt * 8 + 5]), pack_bf2(p[tt * 8 + 6], p[tt * 8 + 7])};
+                pf[qb][kb][tt] = u32x4{pack_bf2(p[tt * 8 + 0], p[tt * 8 + 1]), pack_bf2(p[tt * 8 + 2], p[tt * 8 + 3]),
+                                       pack_bf2(p[tt * 8 + 4], p[tt * 8 + 5]), pack_bf2(p[tt * 8 + 6], p[tt * 8 + 7])};
         }
         return ps0 + ps1;
     };
-    // exact softmax step of q-block qb on s[P] (first tile, masked tiles, lazy-max overflow): optional mask, exact tile max,
-    // re-base of the running max (O, l, the scores — and the NEXT tile's scores in s[P ^ 1] when they were computed against
-    // the old max), exp / pack. All of PV up to the previous tile must be in O.
-    auto exact_step = [&](auto pc, auto qc, bool need_mask, int kv0, int q0w, int kv_lo, bool shift_next) __attribute__((always_inline)) {
-        constexpr int P = decltype(pc)::value, qb = decltype(qc)::value;
+    // exact softmax preparation of q-block qb's scores (first tile, masked tiles, lazy-max overflow): optional mask, exact tile
+    // max, re-base of the running max where it grew — O (complete up to the previous tile by construction of the schedule), l,
+    // the scores, the -m start. The lazy exponentiation that follows is then exact.
+    auto exact_prepare = [&](auto qc, bool need_mask, bool scale_o, int kv0, int q0w, int kv_lo) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value;
         if (need_mask) {
             const int qi = q0w + qb * 32 + l31;
             const int lim = CAUSAL ? min(kv_len - 1, max(qi + coff, kv_lo)) : kv_len - 1;
@@ -272,14 +432,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + kb * 32 + ((r >> 3) << 4) + h * 8 + (r & 7);
-                    s[P][qb][kb][r] = (kv <= lim && kv >= kv_lo) ? s[P][qb][kb][r] : -INFINITY;
+                    s[qb][kb][r] = (kv <= lim && kv >= kv_lo) ? s[qb][kb][r] : -INFINITY;
                 }
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[P][qb][kb][r]);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // relative to m_base = -negm (0 while m_run is still -inf)
         // (m_base - m_run) is 0 once the row has a finite max and +inf before: NaN / +inf also land in the branch
         if (!__all(mx + (-negm[qb][0] - m_run[qb]) <= V4_RESCALE_THR)) {
@@ -290,183 +450,135 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float shift = m_base - m_nu;
             m_run[qb] = m_new;
             l_run[qb] *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
+            if (scale_o) {          // O of this q-block through the arch file (drained MFMAs on both sides: the callers' v4_drain)
+                v4_drain();
+                v4_for<0, 32>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rc)::value;
+                    v4_o_write<32 * qb + r>(v4_o_read<32 * qb + r>() * alpha);
+                });
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[P][qb][kb][r] += shift;
-            if (shift_next) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[P ^ 1][qb][kb][r] += shift;
-            }
+                for (int r = 0; r < 16; ++r) s[qb][kb][r] += shift;
 #pragma unroll
             for (int r = 0; r < 16; ++r) negm[qb][r] = -m_nu;
         }
-        l_run[qb] += exp_pack(pc, qc);
     };
+    // softmax half-slice m (0..15) of q-block qb: elements 2m, 2m+1 of the 32 scores of this lane — 2 exp | 2 add, 1 cvt_pk. With one
+    // wave per SIMD nothing covers the latency of a result but the wave's own later instructions: the exponentials of slice m issue
+    // in half-bundle m, their sums and pack in half-bundle m + 1.
+    float ps[2][2], pe[2][2];
+    auto sm_exp = [&](auto qc, auto mc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value, m = decltype(mc)::value, kb = m >> 3, r0 = (m & 7) * 2;
+#ifdef V4_KO_SM
+        return;
+#endif
+        pe[m & 1][0] = __builtin_amdgcn_exp2f(s[qb][kb][r0]);
+        pe[m & 1][1] = __builtin_amdgcn_exp2f(s[qb][kb][r0 + 1]);
+    };
+    auto sm_use = [&](auto qc, auto mc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qc)::value, m = decltype(mc)::value, kb = m >> 3, r0 = (m & 7) * 2;
+#ifdef V4_KO_SM
+        return;
+#endif
+        ps[qb][0] += pe[m & 1][0];
+        ps[qb][1] += pe[m & 1][1];
+        pf[qb][kb][r0 >> 3][(r0 & 7) >> 1] = pack_bf2(pe[m & 1][0], pe[m & 1][1]);
+        asm volatile("" : "+v"(pf[qb][kb][r0 >> 3]), "+v"(ps[qb][0]), "+v"(ps[qb][1]));
+    };
+    auto sm_half = [&](auto qc, auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        sm_exp(qc, mc);
+        if constexpr (m > 0) sm_use(qc, std::integral_constant<int, (m > 0 ? m - 1 : 0)>{});
+    };
+    const float lazy_lim = (float)(1u << H16_MAX_LOG2);
 
-    // ---- the fused iteration of the kv loop (unmasked tile j with PV(j-1) pending and tile j+1 to score):
-    //   phase A: 16 MFMAs of O^T += V^T(j-1) P(j-1)  |  exp / sum / pack of q-block 0 of tile j
-    //   phase B: 16 MFMAs of S^T(j+1) = K(j+1) Q^T    |  exp / sum / pack of q-block 1 of tile j
-    // in eight fenced bundles per phase: [fragment read 2 bundles ahead | counted wait | 2 MFMAs | 4 exp, 4 add, 2 cvt_pk]; the
-    // four DMA instructions of the tile V4_AHEAD ahead ride in the first four bundles.
-    auto fused = [&](auto pc, int st_prev, int st_next, bool dma, const Item& DI, int dt, int dstage) __attribute__((always_inline)) -> bool {
-        constexpr int P = decltype(pc)::value;
-        float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        char* dks = smem + dstage * V4_STAGE;
-        const int dbase = (dt * 64 + PFX) * 128;
-        // softmax slice m (0..7) of q-block qb: elements 4m .. 4m+3 of the 32 scores of this lane
-        auto sm_slice = [&](auto qc, auto mc) __attribute__((always_inline)) {
-            constexpr int qb = decltype(qc)::value, m = decltype(mc)::value, kb = m >> 2, r0 = (m & 3) * 4;
-            const float p0 = __builtin_amdgcn_exp2f(s[P][qb][kb][r0]), p1 = __builtin_amdgcn_exp2f(s[P][qb][kb][r0 + 1]);
-            const float p2 = __builtin_amdgcn_exp2f(s[P][qb][kb][r0 + 2]), p3 = __builtin_amdgcn_exp2f(s[P][qb][kb][r0 + 3]);
-            ps[qb][0] += p0;
-            ps[qb][1] += p1;
-            ps[qb][0] += p2;
-            ps[qb][1] += p3;
-            constexpr int tt = r0 >> 3, w0 = (r0 & 7) >> 1;
-            pf[P][qb][kb][tt][w0] = pack_bf2(p0, p1);
-            pf[P][qb][kb][tt][w0 + 1] = pack_bf2(p2, p3);
-        };
-        // ---- phase A
-        {
-            unsigned va[2] = {vaddr0[0] + (unsigned)(st_prev * V4_STAGE), vaddr0[1] + (unsigned)(st_prev * V4_STAGE)};
-            tr4_t lo[8], hi[8];
-            v4_for<0, 2>([&](auto fc) __attribute__((always_inline)) {
-                constexpr int f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
-                lo[f] = v4_lds_tr<(kb * 32 + tt * 16) * 128>(va[db]);
-                hi[f] = v4_lds_tr<(kb * 32 + tt * 16 + 4) * 128>(va[db]);
-            });
-            v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-                constexpr int f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1, db = f & 1;
-                V4_FENCE;
-                if constexpr (f + 2 < 8) {
-                    constexpr int f2 = f + 2, st2 = f2 >> 1, kb2 = st2 >> 1, tt2 = st2 & 1, db2 = f2 & 1;
-                    lo[f2] = v4_lds_tr<(kb2 * 32 + tt2 * 16) * 128>(va[db2]);
-                    hi[f2] = v4_lds_tr<(kb2 * 32 + tt2 * 16 + 4) * 128>(va[db2]);
-                }
-                if (f < 4 && dma) {         // one DMA instruction of the tile V4_AHEAD ahead per bundle
-                    if (f < 2)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(DI.rsK, LDS_AS(dks + ((f & 1) * 4 + wave) * 1024), 16,
-                                                                 voffK + dbase + (f & 1) * 4096, 0, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(DI.rsV, LDS_AS(dks + 8192 + ((f & 1) * 4 + wave) * 1024), 16,
-                                                                 voffV + dbase + (f & 1) * 4096, 0, 0, 0);
-                }
-                v4_wait_lgkm2<(f + 2 < 8) ? 4 : (f == 6 ? 2 : 0)>(lo[f], hi[f]);
-                const bf16x8 vf = {lo[f][0], lo[f][1], lo[f][2], lo[f][3], hi[f][0], hi[f][1], hi[f][2], hi[f][3]};
-                o[0][db] = MFMA_32x32x16(vf, __builtin_bit_cast(bf16x8, pf[P ^ 1][0][kb][tt]), o[0][db]);
-                o[1][db] = MFMA_32x32x16(vf, __builtin_bit_cast(bf16x8, pf[P ^ 1][1][kb][tt]), o[1][db]);
-                sm_slice(std::integral_constant<int, 0>{}, fc);
-            });
-        }
-        // ---- phase B
-        {
-            unsigned ka[4];
-#pragma unroll
-            for (int kd = 0; kd < 4; ++kd) ka[kd] = kaddr0[kd] + st_next * V4_STAGE;
-            bf16x8 kf[8];
-            v4_for<0, 2>([&](auto fc) __attribute__((always_inline)) {
-                constexpr int f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
-                kf[f] = v4_lds_b128<kb * 4096>(ka[kd]);
-            });
-            v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
-                constexpr int f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
-                V4_FENCE;
-                if constexpr (f + 2 < 8) {
-                    constexpr int f2 = f + 2, kd2 = f2 >> 1, kb2 = f2 & 1;
-                    kf[f2] = v4_lds_b128<kb2 * 4096>(ka[kd2]);
-                }
-                v4_wait_lgkm<(f + 2 < 8) ? 2 : (f == 6 ? 1 : 0)>(kf[f]);
-                s[P ^ 1][0][kb] = MFMA_32x32x16(kf[f], qf[0][kd], kd == 0 ? negm[0] : s[P ^ 1][0][kb]);
-                s[P ^ 1][1][kb] = MFMA_32x32x16(kf[f], qf[1][kd], kd == 0 ? negm[1] : s[P ^ 1][1][kb]);
-                sm_slice(std::integral_constant<int, 1>{}, fc);
-            });
-            V4_FENCE;
-        }
-        const float t0 = ps[0][0] + ps[0][1], t1 = ps[1][0] + ps[1][1];
-        const float lim = (float)(1u << H16_MAX_LOG2);
-        const bool ok = __all(t0 < lim && t1 < lim);
-        if (ok) {
-            l_run[0] += t0;
-            l_run[1] += t1;
-        }
-        return ok;
-    };
+    // the V fragment window multiplies a zero P in the first tile of the first item: no NaN bit patterns in it
+    asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\t"
+                 "v_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\t"
+                 "v_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\t"
+                 "v_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0\n\t"
+                 "v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\t"
+                 "v_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\t"
+                 "v_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\t"
+                 "v_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0"
+                 ::: V4_FR_CLOBBER);
 
-    // ---- cursors: `cur` = the item being computed (tile t of it), `nxt` = the item after it (its Q is prefetched),
-    // `di` = the item the DMA cursor is in (tile dt of it; kd-th item of this workgroup)
-    Item cur, nxt, di;
-    int kc = 0, kdi = 0;
-    decode(0, cur);
-    if (!cur.valid) return;
-    decode(1, nxt);
-    di = cur;
-    int dt = cur.t_lo;
-    auto advance_dma = [&]() __attribute__((always_inline)) {
-        ++dt;
-        if (dt >= di.ntiles) {
-            ++kdi;
-            decode(kdi, di);
-            dt = di.t_lo;
-        }
-    };
-    // prologue: the first V4_AHEAD tiles of the stream and the first item's Q rows
-    int g = 0;
+    // ---- prologue: the first V4_AHEAD tiles of this workgroup's stream and the first item's Q rows
+    int c_b, c_head, c_qb;
+    if (!decode(0, c_b, c_head, c_qb)) return;
+    dma_enter(0);
+    int g = 0;                              // position in the workgroup's tile stream modulo V4_NS: tile g lives in stage g
+    auto ring = [](int gs, int k) { const int x = gs + k; return x >= V4_NS ? x - V4_NS : x; };
 #pragma unroll
     for (int i = 0; i < V4_AHEAD; ++i) {
-        if (di.valid) {
-            issue_tile(di, dt, i % V4_NS);
-            advance_dma();
+        if (d_valid) {
+            dma_tile(i % V4_NS);
+            dma_advance();
         }
     }
-    issue_q(cur);
+    issue_q(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef V4_TIMELINE
+    unsigned tl_t[8] = {}, tl_sum[8] = {}, tl_n = 0, tl_items = 0;
+    const unsigned tl_begin = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+    int ops_prev_after = 0;                 // VMEM operations issued in the previous iteration after its tile DMA
+    int ops_since_q = 0;                    // ... issued after the newest Q prefetch
 
-    int t = cur.t_lo;
-    bool sv = false, pvp = false;          // s[parity] holds QK^T of tile t / P of tile t - 1 waits for its PV
-    int ops_prev_after = 0;                // VMEM operations issued in the previous iteration after its tile DMA
-    int ops_since_q = 1 << 20;             // ... issued after the newest Q prefetch
-    bool q_inflight = false;
-    int q0w = 0;
-    bool wave_active = false;
-    // item entry: Q fragments out of the wave's LDS rows, the folded prefix key / value as the initial softmax state
-    auto enter_item = [&]() __attribute__((always_inline)) {
-        q0w = a.q_row0 + cur.qb * 256 + wave * 64;
-        wave_active = q0w < q_end;
-        const char* qb_ = qbuf;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kd = 0; kd < 4; ++kd)
-                qf[qb][kd] = *reinterpret_cast<const bf16x8*>(qb_ + (qb * 32 + l31) * 128 + ((kd * 2 + h) << 4));
+    for (int kc = 0;; ++kc) {
+        // ---- item entry: Q fragments out of the wave's LDS rows (prefetched), the folded prefix key / value as the initial state
+        const int kv_lo = kv_lo_of(c_b);
+        const int t_lo = kv_lo >> 6, nt = ntiles_of(c_qb, kv_lo);
+        const int q0w = a.q_row0 + c_qb * 256 + wave * 64;
+        const bool wave_active = q0w < q_end;
+        int n_b, n_head, n_qb;
+        const bool n_valid = decode(kc + 1, n_b, n_head, n_qb);
+        v4_wait_vm(ops_since_q);            // the Q rows of this item have landed (a no-op unless the previous item was very short)
+        const int lane_i = v4_lane_opaque(), l31_i = lane_i & 31, h_i = lane_i >> 5;
+        const unsigned qrow_a = qbuf_a + l31_i * 128 + (h_i << 4);          // this lane's chunk h of Q row l31 (q-block 1: + 4096)
+        v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value, qb = f >> 2, kd = f & 3;
+            v4_qfrag_read<f, qb * 4096 + kd * 32>(qrow_a);
+        });
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             m_run[qb] = -INFINITY;
             l_run[qb] = 0.f;
             negm[qb] = zero16;
-            o[qb][0] = zero16;
-            o[qb][1] = zero16;
         }
+        if (!PFX) v4_for<0, 64>([&](auto rc) __attribute__((always_inline)) { v4_o_write<decltype(rc)::value>(0.f); });
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) pf[1][kb][tt] = zero4;      // "P of the tile before the first" of q-block 1: its PV adds nothing
         if (PFX) {
-            // s0 = q . k0 (q carries scale * log2e): this lane holds dims 16 kd + 8 h .. + 8 of its query rows
+            // s0 = q . k0 (q carries scale * log2e): this lane holds dims 16 kd + 8 h .. + 8 of its query rows. LDS reads as asm: a
+            // compiler-visible read behind the LDS-DMA is waited for with vmcnt(0), which would drain the tile ring at every item
+            bf16x8 qv[2][4], k0f[4];
+            u32x2 v0f[2][4];
+            float ov[2][2][16];
+            v4_for<0, 4>([&](auto kc_) __attribute__((always_inline)) {
+                constexpr int kd = decltype(kc_)::value;
+                qv[0][kd] = v4_lds_b128<kd * 32>(qrow_a);
+                qv[1][kd] = v4_lds_b128<4096 + kd * 32>(qrow_a);
+                k0f[kd] = v4_lds_b128<8192 + kd * 32>(qbuf_a + (h_i << 4));
+                v0f[0][kd] = v4_lds_b64<9216 + kd * 16>(qbuf_a + h_i * 8);
+                v0f[1][kd] = v4_lds_b64<9216 + 64 + kd * 16>(qbuf_a + h_i * 8);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V4_FENCE;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 float part = 0.f;
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(qb_ + 8192 + ((kd * 2 + h) << 4));
+                for (int kd = 0; kd < 4; ++kd)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) part = __builtin_fmaf(bf2f((bf16_t)qf[qb][kd][e]), bf2f((bf16_t)kf[e]), part);
-                }
+                    for (int e = 0; e < 8; ++e) part = __builtin_fmaf(bf2f((bf16_t)qv[qb][kd][e]), bf2f((bf16_t)k0f[kd][e]), part);
                 m_run[qb] = part + __shfl_xor(part, 32, 64);
-                l_run[qb] = h == 0 ? 1.0f : 0.f;             // the two halves' l are added at the end
+                l_run[qb] = h_i == 0 ? 1.0f : 0.f;           // the two halves' l are added at the end
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[qb][r] = -m_run[qb];
                 // O0 = v0: register r of d-block d is d index 32 d + (r & 3) + 8 (r >> 2) + 4 h
@@ -474,142 +586,233 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        float v4[4];
-                        ld4(reinterpret_cast<const bf16_t*>(qb_ + 9216) + d * 32 + gq * 8 + h * 4, v4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[qb][d][gq * 4 + r] = v4[r];
+                        ov[qb][d][gq * 4 + 0] = unpk_lo(v0f[d][gq][0]);
+                        ov[qb][d][gq * 4 + 1] = unpk_hi(v0f[d][gq][0]);
+                        ov[qb][d][gq * 4 + 2] = unpk_lo(v0f[d][gq][1]);
+                        ov[qb][d][gq * 4 + 3] = unpk_hi(v0f[d][gq][1]);
                     }
             }
+            v4_for<0, 64>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                v4_o_write<r>(ov[r >> 5][(r >> 4) & 1][r & 15]);
+            });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the Q rows are consumed: the next prefetch may overwrite them
-        sv = false;
-        pvp = false;
-    };
-    enter_item();
-
-    // epilogue of the item: O^T fragments -> rows through the wave's LDS piece -> 16-byte stores (8 rows x 128 B per instruction)
-    auto store_item = [&]() __attribute__((always_inline)) -> int {
-        if (!wave_active) return 0;
+        bool q_issued = false;
+        if (wave_active) {
+            // "phase B(-1)": the K fragments of the item's first tile and q-block 0's scores of it
+            unsigned ka[4];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-            const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-            const int row = qb * 32 + l31;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    *reinterpret_cast<u32x2*>(obuf + row * 128 + (((d * 4 + gq) ^ (row & 7)) << 4) + h * 8) =
-                        u32x2{pack_bf2(o[qb][d][gq * 4 + 0] * inv, o[qb][d][gq * 4 + 1] * inv),
-                              pack_bf2(o[qb][d][gq * 4 + 2] * inv, o[qb][d][gq * 4 + 3] * inv)};
+            for (int kd = 0; kd < 4; ++kd) ka[kd] = kaddr0[kd] + g * V4_STAGE;
+            v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) { k_read(fc, ka); });
+            v4_wait_lgkm_n<0>();
+            v4_drain();                     // negm (VALU) -> MFMA C operand
+            v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) { qk_mfma(Q0, fc); });
+            v4_drain();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int nst = min(8, (q_end - q0w + 7) >> 3);           // wave-uniform
-        bf16_t* const Ow = a.O + ((int64_t)cur.b * a.q_total + q0w) * ((int64_t)a.Hq * 64) + cur.head * 64;
-        const int rr = lane >> 3, c = lane & 7;
-        for (int i = 0; i < nst; ++i) {
-            const int row = i * 8 + rr;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * 128 + ((c ^ (row & 7)) << 4));
-            if (q0w + row < q_end) *reinterpret_cast<u32x4*>(Ow + (int64_t)row * (a.Hq * 64) + c * 8) = v;
-        }
-        return nst;
-    };
 
-    auto iteration = [&](auto pc) __attribute__((always_inline)) -> bool {
-        constexpr int P = decltype(pc)::value;
-        auto pn = std::integral_constant<int, P ^ 1>{};
-        int ops_cur = 0;
-        const bool dma = di.valid;
-        const Item DI = di;
-        const int ddt = dt, dstage = (g + V4_AHEAD) % V4_NS;
-        const int st_cur = g % V4_NS, st_prev = (g + V4_NS - 1) % V4_NS, st_next = (g + 1) % V4_NS;
-        const int kv0 = t * 64;
-        const bool last = t + 1 >= cur.ntiles;
-        const bool skip = !wave_active || (CAUSAL && kv0 > max(q0w + 63 + coff, cur.kv_lo));
-        const bool next_act = !last && wave_active && !(CAUSAL && kv0 + 64 > max(q0w + 63 + coff, cur.kv_lo));
-        const bool need_mask = (kv0 + 64 > kv_len) || kv0 < cur.kv_lo || (CAUSAL && kv0 + 63 > q0w + coff);
-        bool dma_done = false;
-        if (!skip && sv && pvp && !need_mask && next_act) {
-            const bool ok = fused(pc, st_prev, st_next, dma, DI, ddt, dstage);
-            dma_done = true;
-            if (!ok) {          // a row sum reached the lazy limit: redo tile t exactly from its scores (still in s[P])
-                exact_step(pc, std::integral_constant<int, 0>{}, false, kv0, q0w, cur.kv_lo, true);
-                exact_step(pc, std::integral_constant<int, 1>{}, false, kv0, q0w, cur.kv_lo, true);
-            }
-            // P(t) in pf[P] waits for its PV, s[P ^ 1] = QK^T(t + 1)
-        } else {
-            if (dma) issue_tile(DI, ddt, dstage);
-            dma_done = true;
-            if (!skip) {
-                if (pvp) pv_plain(pn, st_prev);
-                if (!sv) qk_plain(pc, st_cur);
-                exact_step(pc, std::integral_constant<int, 0>{}, need_mask, kv0, q0w, cur.kv_lo, false);
-                exact_step(pc, std::integral_constant<int, 1>{}, need_mask, kv0, q0w, cur.kv_lo, false);
-                pvp = true;
-                if (next_act) {
-                    qk_plain(pn, st_next);
-                    sv = true;
-                } else {
-                    sv = false;
+        for (int t = t_lo;; ++t) {
+            V4_TL(0)
+            const int kv0 = t * 64;
+            const bool first = t == t_lo, last = t + 1 >= nt;
+            const int st_cur = g, st_next = ring(g, 1), dstage = ring(g, V4_AHEAD);
+            const bool dma = d_valid;
+#ifdef V4_DBG_ALLACT
+            const bool act = wave_active, next_act = act && !last;
+#else
+            const bool act = wave_active && !(CAUSAL && kv0 > max(q0w + 63 + coff, kv_lo));
+            const bool next_act = act && !last && !(CAUSAL && kv0 + 64 > max(q0w + 63 + coff, kv_lo));
+#endif
+#if defined(V4_DBG_EXACT) && V4_DBG_EXACT == 1
+            const bool need_mask = true;
+#else
+            const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0w + coff);
+#endif
+#ifdef V4_DBG_EXACT
+            const bool exact = true;
+#else
+            const bool exact = first || need_mask;
+#endif
+            const bool have_o = !first || PFX;
+            if (__builtin_expect(act, 1)) {
+#ifdef V4_DBG_DRAIN
+                v4_drain();
+#endif
+                if (__builtin_expect(exact, 0)) {
+                    exact_prepare(Q0, need_mask, have_o, kv0, q0w, kv_lo);
+                    v4_drain();
                 }
-            } else if (pvp) {       // (a wave past its causal extent with a pending tile: cannot happen — its last tile flushes below)
-                pv_plain(pn, st_prev);
-                pvp = false;
+                // ---- phase A
+                {
+                    unsigned ka[4], va[2];
+#pragma unroll
+                    for (int kd = 0; kd < 4; ++kd) ka[kd] = kaddr0[kd] + st_next * V4_STAGE;
+                    va[0] = vaddr0[0] + (unsigned)(st_cur * V4_STAGE);
+                    va[1] = vaddr0[1] + (unsigned)(st_cur * V4_STAGE);
+                    ps[0][0] = ps[0][1] = 0.f;
+                    v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
+                        constexpr int f = decltype(fc)::value;
+                        V4_FENCE;
+                        qk_mfma(Q1, fc);                         // S^T(t, q-block 1), K fragment f of tile t ...
+                        sm_half(Q0, std::integral_constant<int, 2 * f>{});
+                        k_read(fc, ka);                          // ... whose slot takes fragment f of tile t + 1
+                        V4_FENCE;
+                        pv_mfma(Q1, fc);                         // O1^T += V^T(t-1) P1(t-1), V fragment f of tile t - 1 ...
+                        sm_half(Q0, std::integral_constant<int, 2 * f + 1>{});
+                        v_read(fc, va);                          // ... whose slot takes fragment f of tile t
+                    });
+                    V4_FENCE;
+                    sm_use(Q0, std::integral_constant<int, 15>{});
+                }
+                V4_TL(1)
+                {
+                    const float t0 = ps[0][0] + ps[0][1];
+                    if (__builtin_expect(__all(t0 < lazy_lim), 1)) {
+                        l_run[0] += t0;
+                    } else {            // a row sum reached the lazy limit: q-block 0 again, exactly (its scores are intact until phase B)
+                        exact_prepare(Q0, false, true, kv0, q0w, kv_lo);
+                        l_run[0] += exp_pack(Q0);
+                        v4_drain();
+                    }
+                }
+#ifdef V4_DBG_DRAIN
+                v4_drain();
+#endif
+                if (__builtin_expect(exact, 0)) {
+                    v4_drain();
+                    exact_prepare(Q1, need_mask, have_o, kv0, q0w, kv_lo);
+                    v4_drain();
+                }
+                V4_TL(2)
+                // ---- phase B
+                {
+                    ps[1][0] = ps[1][1] = 0.f;
+                    v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
+                        constexpr int f = decltype(fc)::value;
+                        V4_FENCE;
+                        // the 24 fragment reads of phase A went out in the order K0 V0 V0' K1 V1 V1' ...: fragment pair f is read 3 f + 3
+#ifdef V4_SAFE_WAIT
+                        v4_wait_lgkm_n<0>();
+#else
+                        v4_wait_lgkm_n<(21 - 3 * f > 15) ? 15 : 21 - 3 * f>();
+#endif
+                        qk_mfma(Q0, fc);                         // S^T(t+1, q-block 0)
+                        sm_half(Q1, std::integral_constant<int, 2 * f>{});
+                        V4_FENCE;
+                        pv_mfma(Q0, fc);                         // O0^T += V^T(t) P0(t)
+                        sm_half(Q1, std::integral_constant<int, 2 * f + 1>{});
+                        if constexpr (f < 4) dma_piece(fc, dstage);
+                    });
+                    V4_FENCE;
+                    sm_use(Q1, std::integral_constant<int, 15>{});
+                }
+                V4_TL(3)
+                {
+                    const float t1 = ps[1][0] + ps[1][1];
+                    if (__builtin_expect(__all(t1 < lazy_lim), 1)) {
+                        l_run[1] += t1;
+                    } else {
+                        exact_prepare(Q1, false, true, kv0, q0w, kv_lo);
+                        l_run[1] += exp_pack(Q1);
+                        v4_drain();
+                    }
+                }
+                if (__builtin_expect(!next_act, 0)) {    // this wave's last tile of the item: q-block 1's PV of it (the V fragments of tile t are in the window)
+                    v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) { pv_mfma(Q1, fc); });
+                    v4_drain();
+                }
+            } else {
+                dma_tile(dstage);
             }
+            int ops_cur = 0;
+            if (dma) {
+                ops_cur += 4;
+                dma_advance();
+            }
+            // Q rows of the next item: fetched V4_AHEAD - 1 tiles before this item ends (at its first tile when it is shorter)
+            if (__builtin_expect(n_valid && !q_issued && t + V4_AHEAD >= nt, 0)) {
+                issue_q(kc + 1);
+                ops_cur += QOPS;
+                ops_since_q = 0;
+                q_issued = true;
+            } else {
+                ops_since_q += dma ? 4 : 0;
+            }
+            // tile g + 2 of the stream (issued at the top of the previous iteration) must have landed before the barrier:
+            // everything issued after it may stay in flight
+            V4_TL(4)
+            v4_wait_vm(ops_prev_after + ops_cur);
+            V4_TL(5)
+            __builtin_amdgcn_s_barrier();
+            V4_TL(6)
+            V4_TL_ACC
+            ops_prev_after = ops_cur - (dma ? 4 : 0);
+            g = ring(g, 1);
+            if (last) break;
         }
-        if (dma) {
-            ops_cur += 4;
-            advance_dma();
-        }
-        // Q rows of the next item: V4_AHEAD - 1 iterations before this item ends (or at its first tile when it is shorter)
-        if (nxt.valid && !q_inflight && (t >= cur.ntiles - V4_AHEAD || t == cur.t_lo) && t + V4_AHEAD >= cur.ntiles) {
-            issue_q(nxt);
-            ops_cur += QOPS;
-            ops_since_q = 0;
-            q_inflight = true;
-        }
-        bool finished = false;
-        if (last) {
-            if (!skip && pvp) pv_plain(pc, st_cur);          // P(t) of the item's last tile
-            pvp = false;
-            const int nst = store_item();
-            ops_cur += nst;
+
+        // ---- epilogue of the item: O^T fragments -> rows through the wave's LDS piece -> 16-byte stores (8 rows x 128 B each)
+        if (wave_active) {
+            const int lane_e = v4_lane_opaque(), l31_e = lane_e & 31, h_e = lane_e >> 5;
+            char* const obuf_e = smem + V4_OBUF + wave * 8192;
+            float oe[2][2][16];
+            v4_drain();
+            v4_for<0, 64>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                oe[r >> 5][(r >> 4) & 1][r & 15] = v4_o_read<r>();
+            });
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+                const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+                const int row = qb * 32 + l31_e;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<u32x2*>(obuf_e + row * 128 + (((d * 4 + gq) ^ (row & 7)) << 4) + h_e * 8) =
+                            u32x2{pack_bf2(oe[qb][d][gq * 4 + 0] * inv, oe[qb][d][gq * 4 + 1] * inv),
+                                  pack_bf2(oe[qb][d][gq * 4 + 2] * inv, oe[qb][d][gq * 4 + 3] * inv)};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nst = min(8, (q_end - q0w + 7) >> 3);           // wave-uniform
+            bf16_t* const Ow = a.O + ((int64_t)c_b * a.q_total + q0w) * ((int64_t)a.Hq * 64) + c_head * 64;
+            const int rr = lane_e >> 3, c = lane_e & 7;
+            const unsigned o_lane = (unsigned)rr * (unsigned)(a.Hq * 128) + (unsigned)c * 16u;      // byte offset of (row rr, chunk c)
+            for (int i = 0; i < nst; ++i) {
+                const int row = i * 8 + rr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(obuf_e + row * 128 + ((c ^ (row & 7)) << 4));
+#ifndef V4_KO_STORE
+                if (q0w + row < q_end)
+#else
+                if (q0w + row < q_end && a.q_len < 0)
+#endif
+                    *reinterpret_cast<u32x4*>((char*)Ow + (size_t)i * 8u * (size_t)(a.Hq * 128) + o_lane) = v;
+            }
+            ops_prev_after += nst;
             ops_since_q += nst;
         }
-        // end of the iteration: tile g + 2 of the stream (issued at the top of the previous iteration) must have landed before
-        // the barrier — everything issued after it may stay in flight; an item switch also needs the prefetched Q rows
-        int allowed = ops_prev_after + ops_cur;
-        if (last && q_inflight) allowed = min(allowed, ops_since_q);
-        v4_wait_vm(allowed);
-        __builtin_amdgcn_s_barrier();
-        ops_prev_after = ops_cur - (dma ? 4 : 0);
-        if (!(last && q_inflight)) ops_since_q += 0;
-        ++g;
-        if (last) {
-            if (!nxt.valid) {
-                finished = true;
-            } else {
-                cur = nxt;
-                ++kc;
-                decode(kc + 1, nxt);
-                q_inflight = false;
-                t = cur.t_lo;
-                enter_item();
-            }
-        } else {
-            ++t;
-        }
-        (void)dma_done;
-        return finished;
-    };
-
-    while (true) {
-        if (iteration(std::integral_constant<int, 0>{})) break;
-        if (iteration(std::integral_constant<int, 1>{})) break;
+#ifdef V4_TIMELINE
+        ++tl_items;
+#endif
+        if (!n_valid) break;
+        c_b = n_b;
+        c_head = n_head;
+        c_qb = n_qb;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores and any unused prefetch land before the LDS is released
+#ifdef V4_TIMELINE
+    if (blockIdx.x == 0 && lane < 16) {
+        const unsigned tl_total = (unsigned)__builtin_amdgcn_s_memtime() - tl_begin;
+        unsigned v = 0u;
+        for (int i = 0; i < 6; ++i) v = lane == i ? tl_sum[i] : v;
+        v = lane == 6 ? tl_n : lane == 7 ? tl_total : lane == 8 ? tl_items : v;
+        reinterpret_cast<unsigned*>(a.O + (int64_t)wave * ((int64_t)a.Hq * 64))[lane] = v;
+    }
+#endif
+#endif
 }
 
 // returns false when this kernel does not apply (the caller keeps attn_bf16_v2): head_dim 64, row-major V, whole kv tiles in
@@ -638,7 +841,8 @@ bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_v4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, V4_LDS);
     });
     const int cus = gar_num_cus();
-    const int grid = (int)(n_items < cus ? n_items : cus);
+    int grid = (int)(n_items < cus ? n_items : cus);
+    if (const char* e = getenv("GAR_ATTN_V4_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;      // diagnostics
     if (causal) hipLaunchKernelGGL(attn_bf16_v4_kernel<true>, dim3(grid), dim3(256), V4_LDS, s, a);
     else hipLaunchKernelGGL(attn_bf16_v4_kernel<false>, dim3(grid), dim3(256), V4_LDS, s, a);
     return true;

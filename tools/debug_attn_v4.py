@@ -1,0 +1,55 @@
+import sys, os
+sys.path.insert(0, "grasp-any-region_amd")
+import torch
+from gar_amd import hip, ops
+hip.require_device(0)
+dev, dt = "cuda:0", torch.bfloat16
+torch.manual_seed(0)
+def run(B, Hq, Hkv, n, causal, pfx, npad=None, fill=0.0, kv=None):
+    hd = 64
+    npad = npad or (n + 63) // 64 * 64
+    Q = (torch.randn(B, Hq, npad, hd, device=dev) * 0.3).to(dt)
+    K = torch.randn(B, Hkv, npad, hd, device=dev).to(dt)
+    V = torch.randn(B, Hkv, npad, hd, device=dev).to(dt)
+    kv = kv or n
+    npad = max(npad, (kv + 63) // 64 * 64)
+    K = torch.randn(B, Hkv, npad, hd, device=dev).to(dt); V = torch.randn(B, Hkv, npad, hd, device=dev).to(dt)
+    K[:, :, kv:] = fill; V[:, :, kv:] = fill
+    O = torch.zeros(B * n, Hq * hd, device=dev, dtype=dt)
+    ops.attention(Q, K, V, O, B, Hq, Hkv, hd, n, npad, kv, npad, causal=causal, v_row_major=True, kv_prefix=pfx)
+    q = Q[:, :, :n].double() ; k = K[:, :, :kv].double().repeat_interleave(Hq // Hkv, 1); v = V[:, :, :kv].double().repeat_interleave(Hq // Hkv, 1)
+    s = q @ k.transpose(-1, -2) * 0.6931471805599453
+    if causal:
+        s = s.masked_fill(~torch.ones(n, kv, dtype=torch.bool, device=dev).tril(kv - n), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * n, Hq * hd)
+    err = (O.double() - ref).abs()
+    rows = err.amax(1).view(B, n)
+    bad = (rows > 0.05).nonzero()
+    print(f"npad={npad} fill={fill} B={B} Hq={Hq} Hkv={Hkv} n={n} causal={causal} pfx={pfx}: max err {float(err.max()):.4f}; bad rows {bad.shape[0]} of {B*n}; first bad {bad[:6].tolist()}; per-head err {err.view(B*n, Hq, hd).amax((0,2)).tolist()[:8]}")
+    print("   bad row ranges:", ranges([r[1] for r in bad.tolist() if r[0] == 0])[:20], " nan rows:", ranges(torch.isnan(O.double()).any(1).view(B, n)[0].nonzero().flatten().tolist())[:20])
+    if False:
+        full = (torch.softmax(q @ k.transpose(-1, -2) * 0.6931471805599453, -1) @ v).permute(0, 2, 1, 3).reshape(B * n, Hq * hd)
+        i = bad[0].tolist(); i = i[0] * n + i[1]
+        print("   first bad row vs non-causal ref:", float((O[i].double() - full[i]).abs().max()))
+        for sh in (64, 128, 192, 256, 31, 32, 63):
+            s2 = (q @ k.transpose(-1, -2) * 0.6931471805599453).masked_fill(~torch.ones(n, n, dtype=torch.bool, device=dev).tril(sh), float("-inf"))
+            r2 = (torch.softmax(s2, -1) @ v).permute(0, 2, 1, 3).reshape(B * n, Hq * hd)
+            print(f"   vs causal with +{sh} extra keys: row err {float((O[i].double() - r2[i]).abs().max()):.4f}; all-bad-rows max {float((O.double() - r2)[(rows > 0.05).view(-1)].abs().max()):.4f}")
+    if bad.shape[0]:
+        r = bad[0].tolist(); i = r[0]*n + r[1]
+        print("   cols bad in first bad row:", (err[i] > 0.05).nonzero().flatten().tolist()[:40])
+def ranges(rows):
+    out, st, pv = [], None, None
+    for r in rows:
+        if st is None: st = pv = r
+        elif r == pv + 1: pv = r
+        else: out.append((st, pv)); st = pv = r
+    if st is not None: out.append((st, pv))
+    return out
+for _ in range(3):
+    run(1, 1, 1, 256, True, 0)
+for _ in range(2):
+    run(1, 1, 1, 256, True, 0, 512)
+run(2, 4, 2, 333, True, 0)
+run(1, 2, 1, 768, True, 0)
+run(1, 1, 1, 256, True, 0, 512, 0.0, 512)
