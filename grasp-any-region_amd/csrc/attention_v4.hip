@@ -169,41 +169,48 @@ __device__ __forceinline__ void v4_wait_lgkm_a2(tr4_t& x, tr4_t& y) {
 #define V4_KF0 192
 #define V4_VF0 224
 #define V4_FR_CLOBBER "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define V4_O_CLOBBER_ONLY "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+#define V4_QF_CLOBBER_ONLY "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+#define V4_OWNED V4_O_CLOBBER_ONLY, V4_QF_CLOBBER_ONLY, V4_FR_CLOBBER
+#define V4_O_CLOBBER V4_OWNED
+#define V4_QF_CLOBBER V4_OWNED
 template <int F, int OFF>
 __device__ __forceinline__ void v4_kfrag_read(unsigned addr) {          // K fragment F <- LDS
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%3" ::"v"(addr), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(OFF)
-                 : V4_FR_CLOBBER);
+                 : V4_OWNED);
 }
 template <int F, int HALF, int OFF>
 __device__ __forceinline__ void v4_vfrag_read(unsigned addr) {          // half HALF (kv rows +0..3 / +4..7 of the step) of V fragment F
     asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%3" ::"v"(addr), "i"(V4_VF0 + 4 * F + 2 * HALF), "i"(V4_VF0 + 4 * F + 2 * HALF + 1),
                  "i"(OFF)
-                 : V4_FR_CLOBBER);
+                 : V4_OWNED);
 }
 template <int N>
 __device__ __forceinline__ void v4_wait_lgkm_n() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : V4_FR_CLOBBER);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : V4_OWNED);
 }
 // O (a[0:63]: q-block qb, d block db at 32 qb + 16 db) and the Q fragments (a[64:95]: q-block qb, k-step kd at 64 + 16 qb + 4 kd) are
 // asm-owned too: as "+a" operands the compiler kept O in arch VGPRs and copied it into the accumulator file around every asm
 // block (70 v_accvgpr moves per phase). Compiler code reaches O only through v4_o_read / v4_o_write (item entry, re-base, epilogue).
 #define V4_O0 0
 #define V4_QF0 64
-#define V4_O_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
-#define V4_QF_CLOBBER "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+// every statement that touches an owned range declares ALL of them clobbered: the compiler then keeps nothing of its own in
+// a[0:95] / a[192:255] across the kv loop (tests/test_abi.py audits the ISA: no compiler v_accvgpr_* on an owned register)
 // S^T (arch VGPRs) = K fragment F x Q fragment (q-block QB, k-step F >> 1) (+ C)
 template <int QB, int F>
 __device__ __forceinline__ void v4_mfma_qk_first(f32x16& d, const f32x16& c) {
     asm volatile(V4_MFMA_OP " %0, a[%c2:%c3], a[%c4:%c5], %1"
                  : "=&v"(d)
                  : "v"(c), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)),
-                   "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3));
+                   "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3)
+                 : V4_OWNED);
 }
 template <int QB, int F>
 __device__ __forceinline__ void v4_mfma_qk_acc(f32x16& d) {
     asm volatile(V4_MFMA_OP " %0, a[%c1:%c2], a[%c3:%c4], %0"
                  : "+v"(d)
-                 : "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3));
+                 : "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3)
+                 : V4_OWNED);
 }
 // O^T (q-block QB, d block F & 1) += V fragment F x P
 template <int QB, int F>
@@ -212,10 +219,43 @@ __device__ __forceinline__ void v4_mfma_pv(const u32x4& pb) {
                  "i"(V4_O0 + 32 * QB + 16 * (F & 1) + 15), "i"(V4_VF0 + 4 * F), "i"(V4_VF0 + 4 * F + 3)
                  : V4_O_CLOBBER);
 }
+// The half-bundles of the kv loop: [2 v_exp_f32 of the OTHER q-block's scores | one MFMA] as ONE statement. A lone wave issues about
+// one instruction per 4-5 cycles whatever its type, so a 32-cycle MFMA shadows ~5 issue slots (the guide's budget) — a separate
+// `s_nop` in front of every MFMA would take one of them; here the two exponentials the slice needs anyway are the wait states
+// between a compiler copy of an operand and the MFMA's read of it.
+#if GAR_HALF_F16
+#define V4_MFMA_RAW "v_mfma_f32_32x32x16_f16"
+#else
+#define V4_MFMA_RAW "v_mfma_f32_32x32x16_bf16"
+#endif
+template <int QB, int F>
+__device__ __forceinline__ void v4_hb_qk_first(f32x16& d, const f32x16& c, float& p0, float& p1, float s0, float s1) {
+    asm volatile("v_exp_f32 %1, %4\n\tv_exp_f32 %2, %5\n\t" V4_MFMA_RAW " %0, a[%c6:%c7], a[%c8:%c9], %3"
+                 : "=&v"(d), "=&v"(p0), "=&v"(p1)
+                 : "v"(c), "v"(s0), "v"(s1), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)),
+                   "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3)
+                 : V4_OWNED);
+}
+template <int QB, int F>
+__device__ __forceinline__ void v4_hb_qk_acc(f32x16& d, float& p0, float& p1, float s0, float s1) {
+    asm volatile("v_exp_f32 %1, %3\n\tv_exp_f32 %2, %4\n\t" V4_MFMA_RAW " %0, a[%c5:%c6], a[%c7:%c8], %0"
+                 : "+v"(d), "=&v"(p0), "=&v"(p1)
+                 : "v"(s0), "v"(s1), "i"(V4_KF0 + 4 * F), "i"(V4_KF0 + 4 * F + 3), "i"(V4_QF0 + 16 * QB + 4 * (F >> 1)),
+                   "i"(V4_QF0 + 16 * QB + 4 * (F >> 1) + 3)
+                 : V4_OWNED);
+}
+template <int QB, int F>
+__device__ __forceinline__ void v4_hb_pv(const u32x4& pb, float& p0, float& p1, float s0, float s1) {
+    asm volatile("v_exp_f32 %0, %3\n\tv_exp_f32 %1, %4\n\t" V4_MFMA_RAW " a[%c5:%c6], a[%c7:%c8], %2, a[%c5:%c6]"
+                 : "=&v"(p0), "=&v"(p1)
+                 : "v"(pb), "v"(s0), "v"(s1), "i"(V4_O0 + 32 * QB + 16 * (F & 1)), "i"(V4_O0 + 32 * QB + 16 * (F & 1) + 15),
+                   "i"(V4_VF0 + 4 * F), "i"(V4_VF0 + 4 * F + 3)
+                 : V4_O_CLOBBER);
+}
 template <int R>
 __device__ __forceinline__ float v4_o_read() {
     float x;
-    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(V4_O0 + R));
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(V4_O0 + R) : V4_OWNED);
     return x;
 }
 template <int R>
@@ -487,10 +527,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         pf[qb][kb][r0 >> 3][(r0 & 7) >> 1] = pack_bf2(pe[m & 1][0], pe[m & 1][1]);
         asm volatile("" : "+v"(pf[qb][kb][r0 >> 3]), "+v"(ps[qb][0]), "+v"(ps[qb][1]));
     };
-    auto sm_half = [&](auto qc, auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value;
-        sm_exp(qc, mc);
-        if constexpr (m > 0) sm_use(qc, std::integral_constant<int, (m > 0 ? m - 1 : 0)>{});
+    // half-bundle m of a phase: the MFMA of q-block QM (QK^T fragment f of q-block QM, or its PV fragment f) with the exponentials of
+    // slice m of q-block QS inside the same statement; the sums / pack of slice m - 1 behind it
+    auto hb_qk = [&](auto qmc, auto fc, auto qsc, auto mc) __attribute__((always_inline)) {
+        constexpr int qm = decltype(qmc)::value, f = decltype(fc)::value, kd = f >> 1, kb = f & 1;
+        constexpr int qs = decltype(qsc)::value, m = decltype(mc)::value, skb = m >> 3, r0 = (m & 7) * 2;
+#if defined(V4_KO_SM) || defined(V4_KO_MFMA)
+        qk_mfma(qmc, fc);
+        sm_exp(qsc, mc);
+#else
+        if constexpr (kd == 0) v4_hb_qk_first<qm, f>(s[qm][kb], negm[qm], pe[m & 1][0], pe[m & 1][1], s[qs][skb][r0], s[qs][skb][r0 + 1]);
+        else v4_hb_qk_acc<qm, f>(s[qm][kb], pe[m & 1][0], pe[m & 1][1], s[qs][skb][r0], s[qs][skb][r0 + 1]);
+#endif
+        if constexpr (m > 0) sm_use(qsc, std::integral_constant<int, (m > 0 ? m - 1 : 0)>{});
+    };
+    auto hb_pv = [&](auto qmc, auto fc, auto qsc, auto mc) __attribute__((always_inline)) {
+        constexpr int qm = decltype(qmc)::value, f = decltype(fc)::value, st = f >> 1, kb = st >> 1, tt = st & 1;
+        constexpr int qs = decltype(qsc)::value, m = decltype(mc)::value, skb = m >> 3, r0 = (m & 7) * 2;
+#if defined(V4_KO_SM) || defined(V4_KO_MFMA)
+        pv_mfma(qmc, fc);
+        sm_exp(qsc, mc);
+#else
+        v4_hb_pv<qm, f>(pf[qm][kb][tt], pe[m & 1][0], pe[m & 1][1], s[qs][skb][r0], s[qs][skb][r0 + 1]);
+#endif
+        if constexpr (m > 0) sm_use(qsc, std::integral_constant<int, (m > 0 ? m - 1 : 0)>{});
     };
     const float lazy_lim = (float)(1u << H16_MAX_LOG2);
 
@@ -503,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  "v_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\t"
                  "v_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\t"
                  "v_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0"
-                 ::: V4_FR_CLOBBER);
+                 ::: V4_OWNED);
 
     // ---- prologue: the first V4_AHEAD tiles of this workgroup's stream and the first item's Q rows
     int c_b, c_head, c_qb;
@@ -611,33 +671,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             v4_drain();
         }
 
-        for (int t = t_lo;; ++t) {
+        // one tile of the item. STEADY (compile-time): a tile every wave of the workgroup takes unmasked and lazily, that is neither the
+        // item's first nor among its last V4_AHEAD — no flag, no cursor decision, a constant vmcnt: the hot loop's scalar code and
+        // branches vanish (a lone wave pays ~100 cycles of refetch per taken branch and ~4 cycles per instruction of any kind)
+        auto tile_iter = [&](auto steady_c, int t) __attribute__((always_inline)) -> bool {
+            constexpr bool ST = decltype(steady_c)::value;
             V4_TL(0)
             const int kv0 = t * 64;
-            const bool first = t == t_lo, last = t + 1 >= nt;
+            const bool first = !ST && t == t_lo, last = !ST && t + 1 >= nt;
             const int st_cur = g, st_next = ring(g, 1), dstage = ring(g, V4_AHEAD);
-            const bool dma = d_valid;
-#ifdef V4_DBG_ALLACT
-            const bool act = wave_active, next_act = act && !last;
-#else
-            const bool act = wave_active && !(CAUSAL && kv0 > max(q0w + 63 + coff, kv_lo));
-            const bool next_act = act && !last && !(CAUSAL && kv0 + 64 > max(q0w + 63 + coff, kv_lo));
-#endif
-#if defined(V4_DBG_EXACT) && V4_DBG_EXACT == 1
-            const bool need_mask = true;
-#else
-            const bool need_mask = (kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0w + coff);
-#endif
-#ifdef V4_DBG_EXACT
-            const bool exact = true;
-#else
+            const bool act = ST ? wave_active : wave_active && !(CAUSAL && kv0 > max(q0w + 63 + coff, kv_lo));
+            const bool next_act = ST ? act : act && !last && !(CAUSAL && kv0 + 64 > max(q0w + 63 + coff, kv_lo));
+            const bool need_mask = !ST && ((kv0 + 64 > kv_len) || kv0 < kv_lo || (CAUSAL && kv0 + 63 > q0w + coff));
             const bool exact = first || need_mask;
-#endif
             const bool have_o = !first || PFX;
             if (__builtin_expect(act, 1)) {
-#ifdef V4_DBG_DRAIN
-                v4_drain();
-#endif
                 if (__builtin_expect(exact, 0)) {
                     exact_prepare(Q0, need_mask, have_o, kv0, q0w, kv_lo);
                     v4_drain();
@@ -653,12 +701,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     v4_for<0, 8>([&](auto fc) __attribute__((always_inline)) {
                         constexpr int f = decltype(fc)::value;
                         V4_FENCE;
-                        qk_mfma(Q1, fc);                         // S^T(t, q-block 1), K fragment f of tile t ...
-                        sm_half(Q0, std::integral_constant<int, 2 * f>{});
+                        hb_qk(Q1, fc, Q0, std::integral_constant<int, 2 * f>{});       // S^T(t, q-block 1), K fragment f of tile t ...
                         k_read(fc, ka);                          // ... whose slot takes fragment f of tile t + 1
                         V4_FENCE;
-                        pv_mfma(Q1, fc);                         // O1^T += V^T(t-1) P1(t-1), V fragment f of tile t - 1 ...
-                        sm_half(Q0, std::integral_constant<int, 2 * f + 1>{});
+                        hb_pv(Q1, fc, Q0, std::integral_constant<int, 2 * f + 1>{});   // O1^T += V^T(t-1) P1(t-1), V fragment f of tile t - 1 ...
                         v_read(fc, va);                          // ... whose slot takes fragment f of tile t
                     });
                     V4_FENCE;
@@ -675,9 +721,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         v4_drain();
                     }
                 }
-#ifdef V4_DBG_DRAIN
-                v4_drain();
-#endif
                 if (__builtin_expect(exact, 0)) {
                     v4_drain();
                     exact_prepare(Q1, need_mask, have_o, kv0, q0w, kv_lo);
@@ -696,11 +739,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
                         v4_wait_lgkm_n<(21 - 3 * f > 15) ? 15 : 21 - 3 * f>();
 #endif
-                        qk_mfma(Q0, fc);                         // S^T(t+1, q-block 0)
-                        sm_half(Q1, std::integral_constant<int, 2 * f>{});
+                        hb_qk(Q0, fc, Q1, std::integral_constant<int, 2 * f>{});       // S^T(t+1, q-block 0)
                         V4_FENCE;
-                        pv_mfma(Q0, fc);                         // O0^T += V^T(t) P0(t)
-                        sm_half(Q1, std::integral_constant<int, 2 * f + 1>{});
+                        hb_pv(Q0, fc, Q1, std::integral_constant<int, 2 * f + 1>{});   // O0^T += V^T(t) P0(t)
                         if constexpr (f < 4) dma_piece(fc, dstage);
                     });
                     V4_FENCE;
@@ -724,11 +765,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {
                 dma_tile(dstage);
             }
-            int ops_cur = 0;
-            if (dma) {
-                ops_cur += 4;
+            if (ST) {
                 dma_advance();
+                ops_since_q += 4;
+                V4_TL(4)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // tile g + 2 landed; the newest tile DMA stays in flight
+                V4_TL(5)
+                __builtin_amdgcn_s_barrier();
+                V4_TL(6)
+                V4_TL_ACC
+                g = ring(g, 1);
+                return false;
             }
+            int ops_cur = 4;
+            dma_advance();
             // Q rows of the next item: fetched V4_AHEAD - 1 tiles before this item ends (at its first tile when it is shorter)
             if (__builtin_expect(n_valid && !q_issued && t + V4_AHEAD >= nt, 0)) {
                 issue_q(kc + 1);
@@ -736,7 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 ops_since_q = 0;
                 q_issued = true;
             } else {
-                ops_since_q += dma ? 4 : 0;
+                ops_since_q += 4;
             }
             // tile g + 2 of the stream (issued at the top of the previous iteration) must have landed before the barrier:
             // everything issued after it may stay in flight
@@ -746,9 +796,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_s_barrier();
             V4_TL(6)
             V4_TL_ACC
-            ops_prev_after = ops_cur - (dma ? 4 : 0);
+            ops_prev_after = ops_cur - 4;
             g = ring(g, 1);
-            if (last) break;
+            return last;
+        };
+        // tiles t_lo < t < t_hi are STEADY for every wave: unmasked for the block's first row (causal), whole (kv tail), and followed by
+        // at least V4_AHEAD more tiles of the item (the DMA cursor stays inside it, the next item's Q rows are not due yet)
+        int t_hi = min(nt - V4_AHEAD, kv_len >> 6);
+        if (CAUSAL) t_hi = min(t_hi, (a.q_row0 + c_qb * 256 + coff + 1) >> 6);
+        for (int t = t_lo;;) {
+            if (t > t_lo && t < t_hi && ops_prev_after == 0) {
+                do {
+                    tile_iter(std::true_type{}, t);
+                    ++t;
+                } while (t < t_hi);
+                continue;
+            }
+            if (tile_iter(std::false_type{}, t)) break;
+            ++t;
         }
 
         // ---- epilogue of the item: O^T fragments -> rows through the wave's LDS piece -> 16-byte stores (8 rows x 128 B each)
@@ -815,15 +880,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+// Opt-in (round 5): the kernel is parity-green but slower than v2 at head_dim 64 (profiles/r5_attention_v4.txt).
+// Initial state from the environment (GAR_ATTN_V4=1), changed at run time through gar_attention_v4_enable().
+static int v4_switch(int set) {
+    static int state = [] {
+        const char* e = getenv("GAR_ATTN_V4");
+        return e ? (atoi(e) != 0) : 0;
+    }();
+    const int prev = state;
+    if (set >= 0) state = set != 0;
+    return prev;
+}
+extern "C" int gar_attention_v4_enable(int on) { return v4_switch(on); }
+
 // returns false when this kernel does not apply (the caller keeps attn_bf16_v2): head_dim 64, row-major V, whole kv tiles in
 // the slab (kv_stride % 64 == 0), at least 256 query rows per item.
 bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd, int q_row0,
                           int q_len, int q_total, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s) {
-    static const int enabled = [] {
-        const char* e = getenv("GAR_ATTN_V4");
-        return e ? atoi(e) : 1;
-    }();
+    const int enabled = v4_switch(-1);
     if (!enabled || hd != 64 || q_len < 256 || (int64_t)kv_stride * 128 >= ((int64_t)1 << 31) || (int64_t)q_pad * 128 >= ((int64_t)1 << 31))
         return false;
     if ((kv_stride & 63) != 0 || Hq % Hkv != 0) return false;

@@ -18,7 +18,7 @@ GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
  EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GarError(RuntimeError):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp], _i),
     "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
+    "gar_attention_v4_enable": ([_i], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
     "gar_attention_decode": ([_i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gar_attention_decode_qkv": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp], _i),
