@@ -214,6 +214,21 @@ def cpu_baseline(cfg, W, sample, new_tokens, threads):
 CPU_DECODE_STEPS = 16
 
 
+def parity_pins():
+    """which pieces of the oracle are pinned by fixtures present in tests/golden/ (VERDICT r4 #7): the day a box has timm / torchvision
+    and tools/capture_ext_goldens.py has been run, the record changes without anyone reading test logs"""
+    g = os.path.join(ROOT, "tests", "golden")
+    have = lambda *names: all(os.path.exists(os.path.join(g, n)) for n in names)
+    pins = {"llama": have("llama_tiny.npz", "llama_tiny_padded.npz", "llama_inv_freq.npz"), "projector": have("projector_tiny.npz"),
+            "helpers": have("ref_helpers.json", "rle_samples.json"), "torch_ops": have("torch_ops.npz"),
+            "ext_timm_eva": have("ext_timm_eva.npz"), "ext_tv_roi_align": have("ext_tv_roi_align.npz")}
+    pins["unpinned"] = [k for k, v in pins.items() if not v]
+    pins["note"] = ("fixtures generated by the reference's own code / its pinned dependencies (tools/make_goldens.py, "
+                    "tools/capture_ext_goldens.py); ext_* need timm==1.0.19 / torchvision, absent from this image: the ViT forward and "
+                    "roi_align restatements of oracle/gar_oracle.py are parity-unpinned until they exist")
+    return pins
+
+
 def pick_synthetic_eos(streams, max_new, target_mean_frac=0.4, max_ids=12):
     """EOS ids for random-init weights: token ids out of the regions' own free-running streams, most widely shared first, until
     the captions they cut average ``target_mean_frac * max_new`` tokens — mixed lengths, from a few tokens to the cap."""
@@ -615,7 +630,7 @@ def main(argv=None, runtime=None):
                 "algorithmic_bytes_per_launch": nb / cnt, "time_share_of_step": sec / elapsed}
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
         # WRITE_SIZE cannot share a pass), folded by tools/pmc_summary.py and committed under profiles/ (newest round first)
-        for rnd in ("r4", "r3", "r2", "r1"):
+        for rnd in ("r5", "r4", "r3", "r2", "r1"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if args.workload == "single" and args.model == "gar_1b" and os.path.exists(pmc):
                 try:
@@ -670,6 +685,7 @@ def main(argv=None, runtime=None):
                        "weights": f"seeded synthetic {mname}", "parallelism": f"dp{world} (replica per GPU, RCCL weight "
                                                                               f"broadcast + caption gather)"},
             "roofline": roof,
+            "parity_pins": parity_pins(),
             **dp.describe(),
             "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
             "weight_broadcast": {"seconds": bcast_s, "bytes": bcast_bytes, "collectives": bcast_n,

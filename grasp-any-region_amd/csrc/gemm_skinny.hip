@@ -34,9 +34,18 @@
 // ROWS = 8 (NT == 1 only): a block owns EIGHT weight rows instead of sixteen — the upper half of its MFMA tile is never staged
 // nor stored — so that a narrow output (N = 2048: 128 sixteen-row tiles) still gives every CU a block: Llama's o / down at
 // M <= 16 stream from 256 CUs instead of 128 (tools/bench_skinny.py, round 4).
-template <int EPI, int NT, int MT, int NORM, bool STAGED, int ROWS = 16>
+// DEEP (ROWS = 8, one row tile of at most EIGHT activation rows, no norm prologue: Llama's o / down at decode batches <= 8): weights AND
+// activations ride a ring of SKINNY_DEEP K steps, 1 KiB each (8 rows x 128 B: the upper half of both MFMA tiles is a duplicate of the
+// lower one and never stored). The staged path above re-arms the activation tile ONE step ahead; vmcnt retires in order, so waiting
+// for it also waits for every weight DMA issued before it and a wave has ~2 KiB in flight however deep its weight ring is —
+// `down` (K = 8192: 16 K steps per wave) paid a memory latency every other step: 12.3 us for 33.5 MB at M = 1 (2.7 TB/s).
+#ifndef SKINNY_DEEP
+#define SKINNY_DEEP 8
+#endif
+template <int EPI, int NT, int MT, int NORM, bool STAGED, int ROWS = 16, bool DEEP = false>
 __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) void skinny_mt_bf16_kernel(const gar_gemm_params p) {
     static_assert(ROWS == 16 || (ROWS == 8 && NT == 1), "half tiles are built for one weight tile per block");
+    static_assert(!DEEP || (ROWS == 8 && NT == 1 && MT == 1 && NORM == 0 && STAGED), "the deep ring is built for the half-tile GEMV without a norm prologue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,7 +243,45 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
         }
     };
     int ks = ks0;
-    if (STAGED) {
+    if constexpr (DEEP) {
+        constexpr int DW = SKINNY_DEEP;
+        char* ring = smem + wave * (DW * 2048);
+        const int drow = lane >> 3, dch = ((lane & 7) ^ ((drow >> 1) & 7)) << 4;
+        const int dvW = (int)((unsigned)(n0 + drow) * rbW) + dch, dvX = (int)((unsigned)drow * rbX) + dch;
+        auto issue = [&](int k_) {
+            char* slot = ring + ((k_ - ks0) % DW) * 2048;
+            const unsigned k0b = (unsigned)k_ * 128u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_AS(slot), 16, dvW + (int)k0b, 0, 0, SK_W_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_AS(slot + 1024), 16, dvX + (int)k0b, 0, 0, 0);
+        };
+        // fragment rows 8..15 read rows 0..7 again (defined data; their outputs are never stored)
+        const int fr = frow & 7;
+        const int d0 = fr * 128 + (((2 * fq) ^ ((fr >> 1) & 7)) << 4), d1 = fr * 128 + (((2 * fq + 1) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+        for (int d = 0; d < DW - 1; ++d)
+            if (ks0 + d < ks1) issue(ks0 + d);
+        for (; ks < ks1; ++ks) {
+            if (ks + DW - 1 < ks1) issue(ks + DW - 1);
+            // everything up to step ks has landed; the steps issued behind it (two DMA instructions each) stay in flight
+            const int rem = min(DW - 1, ks1 - 1 - ks);
+            if (__builtin_expect(rem == DW - 1, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (DW - 1)) : "memory");
+            else if (rem >= 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (rem == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (rem == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* slot = ring + ((ks - ks0) % DW) * 2048;
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(slot + d0), w1 = *reinterpret_cast<const bf16x8*>(slot + d1);
+            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(slot + 1024 + d0), x1 = *reinterpret_cast<const bf16x8*>(slot + 1024 + d1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = MFMA_16x16x32(w0, x0, acc[0][0]);
+            acc[0][0] = MFMA_16x16x32(w1, x1, acc[0][0]);
+        }
+        __syncthreads();                          // the merge buffer below aliases the rings
+    } else if (STAGED) {
         if (ROWS == 8) {
             // rows 8..15 of every weight slot are never staged: zero them once so that the MFMAs whose output rows are discarded
             // consume defined operands (no NaN / Inf bit patterns out of whatever the LDS held). One 1-KiB store per
@@ -336,7 +383,7 @@ __global__ __launch_bounds__((NT >= 4 || (NORM == 1 && MT >= 4)) ? 512 : 1024) v
     }
 }
 
-template <int EPI, int MT, int NT, int ROWS = 16>
+template <int EPI, int MT, int NT, int ROWS = 16, bool DEEP = false>
 static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
     const int nb = (p.N + ROWS * NT - 1) / (ROWS * NT);
     const int nsplit = (EPI == GAR_EPI_NONE && p.split_k > 1) ? p.split_k : 1;
@@ -390,6 +437,29 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
 #undef LAUNCH_SK
 }
 
+// the deep-ring half-tile GEMV (DEEP): M <= 8 rows, narrow output, no norm prologue. false = not applicable.
+template <int EPI>
+static bool launch_skinny_deep(const gar_gemm_params& p, hipStream_t s) {
+    static const int enabled = [] {
+        const char* e = getenv("GAR_SKINNY_DEEP");          // A/B switch (tools/bench_skinny.py)
+        return e ? atoi(e) : 1;
+    }();
+    const bool staged = ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) && ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
+    if (!enabled || !staged || p.M > 8 || p.norm_w || p.norm_folded || p.split_k > 1) return false;
+    const int nb = (p.N + 7) / 8, ksteps = p.K / 64;
+    constexpr int MAXLDS = 139264;
+    static gar_once_per_device attr_once;
+    attr_once.run([&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_mt_bf16_kernel<EPI, 1, 1, 0, true, 8, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+    });
+    int nw = 4;
+    while (nw < 8 && nb * nw < 2048 && ksteps / (nw * 2) >= 2) nw *= 2;
+    const int lds = nw * SKINNY_DEEP * 2048;        // >= the merge buffer (nw x 1088 B)
+    hipLaunchKernelGGL((skinny_mt_bf16_kernel<EPI, 1, 1, 0, true, 8, true>), dim3(nb, 1), dim3(nw * 64), lds, s, p);
+    return true;
+}
+
 // NT = weight tiles (16 rows) per block. With several row tiles (M > 16) every block re-reads the activations from
 // L2, MT x the bytes of its weight tile: wide outputs (gate/up, lm_head) use 4 weight tiles per block so one activation
 // fragment serves 4 of them; narrow outputs keep 1 (2 for SwiGLU pairs) for the sake of block count.
@@ -403,7 +473,9 @@ static void launch_skinny_m(const gar_gemm_params& p, hipStream_t s) {
     if (p.M <= 16) {
         // a narrow output: 8-row half tiles so that N / 8 blocks (256 for N = 2048) cover the chip instead of N / 16
         if (NT0 == 1 && p.N <= SK_HALF_MAX_N && p.N % 8 == 0 && p.split_k <= 1) {
-            if constexpr (NT0 == 1) launch_skinny<EPI, 1, 1, 8>(p, s);
+            if constexpr (NT0 == 1) {
+                if (!launch_skinny_deep<EPI>(p, s)) launch_skinny<EPI, 1, 1, 8>(p, s);
+            }
         } else {
             launch_skinny<EPI, 1, NT0>(p, s);
         }

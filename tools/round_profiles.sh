@@ -3,7 +3,7 @@
 # SQ/GRBM counter passes of the GEMM and attention micro-benchmarks, a clock/power trace, and the default bench line.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-R=${R:-r4}
+R=${R:-r5}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof
 mkdir -p $O
 python bench.py --steps 3 --warmup 1 > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
@@ -39,6 +39,8 @@ timeout 900 python bench.py --no-cpu-baseline --workload multi_region --steps 2 
 timeout 900 python bench.py --no-cpu-baseline --workload video --steps 2 > $O/bench_video.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --batch 1 --steps 5 --warmup 2 > $O/bench_batch1.log 2>&1
 tail -1 $O/bench_batch1.log > $O/${R}_bench_batch1.json
+timeout 600 python bench.py --eos-mix > $O/bench_eosmix.log 2>&1
+tail -1 $O/bench_eosmix.log > $O/${R}_bench_eos_mix.json
 tail -1 $O/bench_default.log > $O/${R}_bench_default.json
 tail -1 $O/bench_gar8b.log > $O/${R}_bench_gar8b.json
 tail -1 $O/bench_multi.log > $O/${R}_bench_multi_region.json
