@@ -40,6 +40,10 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
 #define MFMA_16x16x32(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_hw_t, a), __builtin_bit_cast(h16x8_hw_t, b), c, 0, 0, 0)
 #define H16_ONE 0x3C00
+// c + a.lo * b.lo + a.hi * b.hi on packed pairs of the 16-bit type (products exact, fp32 accumulation): v_dot2_f32_f16
+__device__ __forceinline__ float dot2_acc(unsigned int a, unsigned int b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_hw_t, a), __builtin_bit_cast(h16x2_hw_t, b), c, false);
+}
 #define H16_MAX_LOG2 15      /* largest power of two a stored softmax weight may reach (fp16 ends at 65504) */
 #else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned int)v) << 16); }
@@ -55,6 +59,10 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
 #define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define H16_ONE 0x3F80
+// c + a.lo * b.lo + a.hi * b.hi on packed pairs of the 16-bit type (products exact, fp32 accumulation): v_dot2c_f32_bf16
+__device__ __forceinline__ float dot2_acc(unsigned int a, unsigned int b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw_t, a), __builtin_bit_cast(bf16x2_hw_t, b), c, false);
+}
 #define H16_MAX_LOG2 16
 #endif
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }

@@ -65,6 +65,12 @@
 #ifndef PP_W_AUX
 #define PP_W_AUX 0
 #endif
+#ifndef PP_ST_AUX        /* diagnostic builds: cache-policy bits of the epilogue's output stores / residual loads (1 = sc0, 2 = nt, 16 = sc1) */
+#define PP_ST_AUX 0
+#endif
+#ifndef PP_RES_AUX
+#define PP_RES_AUX 0
+#endif
 template <int AUX = 0>
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base,
                                            char* lds, int wave) {
@@ -89,16 +95,18 @@ __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsi
 // (1/128)^2 / 8 * 0.8 = 6e-6 (bf16 rounds at 4e-3 relative), 9 VALU + one ds_read_b64 per element. x >= 8 returns x.
 #define GELU_LUT_N 2048
 #define GELU_LUT_BYTES (GELU_LUT_N * 8)
-// Only the interval INDEX is clamped, not the interpolation weight: beyond the table the last / first interval is
-// extended linearly — gelu(x) = x to fp32 precision for x >= 8 (the last interval's slope is 1) and 0 for x <= -8 (the
-// first entry's slope is stored as 0) — so there is no range test: 7 VALU + one ds_read_b64 per element (9 with one).
+// Only the interval INDEX is clamped: beyond the table the last / first interval is extended linearly — gelu(x) = x to fp32
+// precision for x >= 8 (the last interval's slope is 1) and 0 for x <= -8 (the first entry's slope is stored as 0) — so there
+// is no range test. An entry holds the interval's LINE in table coordinates, (c0, s) with c0 = gelu(x_k) - s k, so that the
+// value is one fma on u itself — neither floor(u) nor the weight u - floor(u) is formed: 5 VALU + one ds_read_b64 per element
+// (fma, med3, cvt, shift, fma; 7 with the (value, slope) form, 9 with a range test). |c0| <= 18: its rounding adds <= 1e-6.
 __device__ __forceinline__ float gelu_lut_u(float u, const char* lut) {          // u = 128 x + 1024: the table coordinate
-    const float fi = __builtin_floorf(__builtin_amdgcn_fmed3f(u, 0.0f, 2047.0f));
-    const float2 e = *reinterpret_cast<const float2*>(lut + ((int)fi << 3));
+    const int k = (int)__builtin_amdgcn_fmed3f(u, 0.0f, 2047.0f);                 // truncation = floor: the operand is >= 0
+    const float2 e = *reinterpret_cast<const float2*>(lut + (k << 3));
     // one v_fma_f32 per element, pinned: left to itself the compiler pairs two elements into a v_pk_fma_f32 and pays three
-    // v_mov to shuffle (value, slope) of the two table entries into operand pairs — 4 instructions where 2 do
+    // v_mov to shuffle (line, slope) of the two table entries into operand pairs — 4 instructions where 2 do
     float r;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(u - fi), "v"(e.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(u), "v"(e.x));
     return r;
 }
 __device__ __forceinline__ float gelu_lut(float x, const char* lut) {
@@ -136,9 +144,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             const int k = tid + 512 * j;
             const float x0 = -8.0f + (float)k * (1.0f / 128.0f);
             const float g0 = gelu_erf(x0), g1 = gelu_erf(x0 + 1.0f / 128.0f);
-            // slopes are per table step; entry 0 extends to x < -8 with slope 0, entry 2047 to x > 8 with slope 1 / 128 per step
-            *reinterpret_cast<float2*>(smem + 2 * PSTAGE + k * 8) =
-                make_float2(g0, k == 0 ? 0.0f : (k == GELU_LUT_N - 1 ? (x0 + 1.0f / 128.0f) - g0 : g1 - g0));
+            // slopes are per table step; entry 0 extends to x < -8 with slope 0, entry 2047 to x > 8 with slope 1 / 128 per step;
+            // stored as the line c0 + s u through (k, g0): c0 = g0 - s k, one rounding
+            const float sl = k == 0 ? 0.0f : (k == GELU_LUT_N - 1 ? (x0 + 1.0f / 128.0f) - g0 : g1 - g0);
+            *reinterpret_cast<float2*>(smem + 2 * PSTAGE + k * 8) = make_float2(__builtin_fmaf(-sl, (float)k, g0), sl);
         }
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         const int rr = lane_e >> 3, ch = lane_e & 7;      // row side: rows rr and 8 + rr of a 16-row step, 8 columns ch*8..
         const int n = n0 + wn * 64 + ch * 8;
         const bool nok = n < p.N;
-        float gam8[8];                                   // LayerScale of this lane's row-side columns (the bias is in the accumulators)
+        float gam8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // LayerScale of this lane's row-side columns (the bias is in the accumulators)
         if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
         // destination element offset and row-dependent load of row-side slot (i, t)
         auto row_of = [&](int i, int t) { return m0 + wm * 128 + i * 16 + t * 8 + rr; };
@@ -567,20 +576,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         // (the base is per TILE — C + mw * ldc — and the slot's row offset (16 i + 8 t) * ld, < 2^24, joins the lane's
         // offset in one v_mad_u32_u24: no 64-bit arithmetic per slot, scalar or vector)
         const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u, n2 = (unsigned)(nok ? n : 0) * 2u;
-        char* const Cw = (char*)p.C + (int64_t)mw * p.ldc * 2;
-        const int mwc = min(mw, p.M - 1);                     // the residual is READ for clamped rows at the M tail
-        const char* const Rw = (const char*)p.residual + (int64_t)mwc * p.ldr * 2;
-        const int r_lim = p.M - 1 - mwc;
-        auto dst_ptr = [&](int i, int t, int m) -> bf16_t* {
-            if (EPI == GAR_EPI_PATCH_POS) {
-                int tile, tok;
-                split_row(m, tile, tok);
-                return (bf16_t*)p.C + ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
-            }
-            if (PP_DIAG_L2STORE) return (bf16_t*)p.C + (int64_t)(m - m0) * p.ldc + (n - n0);     // diagnostic build: L2-resident stores
-            return reinterpret_cast<bf16_t*>(Cw + ((unsigned)(i * 16 + t * 8 + rr) * ldc2 + n2));
+        // LINEAR outputs go through buffer descriptors whose base is the strip's first row and whose extent is the rows of
+        // the strip that exist (<= 128): a store to a row past M is dropped and a residual load from one returns 0 by the
+        // descriptor's range check, a lane whose columns lie past N carries an offset no extent reaches — no exec masking,
+        // no clamps and no 64-bit arithmetic per slot; the slot's row offset joins the lane's 32-bit offset in one add
+        // (in the VGPR offset: the range check does not cover the scalar offset operand).
+        constexpr bool LINEAR = EPI != GAR_EPI_PATCH_POS && EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_QKV_ROPE_LLM;
+        constexpr unsigned OFF_NONE = 0x7fff0000u;
+        // (readfirstlane: min / max / med3 have no scalar form, and a descriptor word that lives in a VGPR is treated as
+        // divergent — a waterfall loop around every access)
+        const int rows_here = LINEAR ? __builtin_amdgcn_readfirstlane(max(min(p.M - mw, 128), 0)) : 0;
+        char* const Cw = PP_DIAG_L2STORE ? (char*)p.C + (int64_t)(wm * 128) * p.ldc * 2 - (int64_t)n0 * 2      // diagnostic build: L2-resident stores
+                                         : (char*)p.C + (int64_t)mw * p.ldc * 2;
+#ifdef PP_DROPSTORE   /* diagnostic build: the whole epilogue runs, but the output descriptor's extent is 0 — every store is issued
+                         and dropped by the range check (what the epilogue costs without its write traffic) */
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cw, 0, 0, 0x00020000);
+#else
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cw, 0, (int)((unsigned)rows_here * ldc2), 0x00020000);
+#endif
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((char*)const_cast<void*>(p.residual) + (int64_t)mw * p.ldr * 2), 0,
+#ifdef PP_DROPRES      /* diagnostic build: residual loads answered (with 0) by the range check — no read traffic */
+            0, 0x00020000);
+#else
+            (int)((EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES) ? (unsigned)rows_here * ldr2 : 0u), 0x00020000);
+#endif
+        const unsigned offC = nok ? (unsigned)rr * ldc2 + n2 : OFF_NONE, offR = nok ? (unsigned)rr * ldr2 + n2 : OFF_NONE;
+        // row statistics (float2 per row and 64-column strip): the same scheme, one lane per row
+        const unsigned st2 = (unsigned)((p.N + 63) >> 6) * 8u;
+        const bool stats_on = STATS_EPI && p.row_stats != nullptr && n0 + wn * 64 < p.N;
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((char*)p.row_stats + ((int64_t)mw * ((p.N + 63) >> 6) + ((n0 >> 6) + wn)) * 8), 0,
+            (int)(stats_on ? (unsigned)rows_here * st2 : 0u), 0x00020000);
+        const unsigned offS = ch == 0 ? (unsigned)rr * st2 : OFF_NONE;
+        auto store_lin = [&](int i, int t, const u32x4& v) {
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsC, (int)(offC + (unsigned)(i * 16 + t * 8) * ldc2), 0, PP_ST_AUX);
         };
-        auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional (clamped) so the prefetch ring carries no exec state
+        auto dst_ptr = [&](int i, int t, int m) -> bf16_t* {           // PATCH_POS only
+            int tile, tok;
+            split_row(m, tile, tok);
+            return (bf16_t*)p.C + ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
+        };
+        auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional so the prefetch ring carries no exec state
             if (EPI == GAR_EPI_PATCH_POS) {
                 const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
                 int tile, tk;
@@ -588,8 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                 const int tok = p.token_offset + max(tk, 0);
                 return *reinterpret_cast<const u32x4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + nc);
             }
-            const int rel = min(i * 16 + t * 8 + rr, r_lim);
-            return *reinterpret_cast<const u32x4*>(Rw + ((unsigned)rel * ldr2 + n2));
+            return __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(offR + (unsigned)(i * 16 + t * 8) * ldr2), 0, PP_RES_AUX);
         };
         // QKV_ROPE: this lane's 8 columns are dims qd..qd+7 of head qh of q (part 0), k (1) or v (2); the rotation of row
         // (token) tok needs the four (sin, cos) pairs of those dims: two 16-byte loads, issued one 16-row step ahead.
@@ -679,6 +715,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                 for (int t = 0; t < 2; ++t) aux[i][t] = aux_load(i, t);
         }
+        // Staging writes of 16-row step i (this lane's fragments of m-tile i). The steps are software-pipelined: step i + 1 is
+        // written right behind step i's read-back — the LDS runs a wave's requests in order, so the read samples the buffer
+        // before the write lands — and its write -> read turnaround passes under step i's arithmetic and stores instead of in
+        // front of step i + 1's. DIRECT outputs (2 KiB per step) alternate between the two halves of the private 4 KiB, so the
+        // GELU / rounding of step i + 1 also runs while step i's rows come back.
+        auto wave_fence = [&]() {
+            // lanes exchange data through LDS inside one wave: the hardware runs a wave's DS instructions in order, the
+            // fences keep the COMPILER from moving a lane's accesses across the hand-over (no instruction is emitted)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto stage_write = [&](int i) {
+            if (DIRECT) {
+                char* const buf = priv + (i & 1) * 2048;
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq) {
+                    float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
+                                  acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
+                    if (EPI == GAR_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = gelu_lut(o[e], glut);
+                    }
+                    *reinterpret_cast<u32x4*>(buf + frow_e * 128 + (((jq * 4 + fq_e) ^ ((frow_e >> 1) & 7)) << 4)) =
+                        u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(priv + frow_e * 256 +
+                                              ((((j >> 1) * 8 + fq_e * 2 + (j & 1)) ^ (frow_e & 15)) << 4)) = acc[i][j];
+            }
+        };
+        stage_write(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (HAS_AUX && i + AH < 8) {
@@ -693,44 +763,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             }
             if (QKVL && l_rot && i + 1 < 8) l_load(i + 1, (i + 1) & 1);
             if (DIRECT) {
-#pragma unroll
-                for (int jq = 0; jq < 2; ++jq) {
-                    float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
-                                  acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
-                    if (EPI == GAR_EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = gelu_lut(o[e], glut);
-                    }
-                    *reinterpret_cast<u32x4*>(priv + frow_e * 128 + (((jq * 4 + fq_e) ^ ((frow_e >> 1) & 7)) << 4)) =
-                        u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const char* const buf = priv + (i & 1) * 2048;
+                wave_fence();
                 u32x4 v2[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int row = t * 8 + rr;
-                    v2[t] = *reinterpret_cast<const u32x4*>(priv + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                    v2[t] = *reinterpret_cast<const u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_fence();
+                if (i + 1 < 8) stage_write(i + 1);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int m = row_of(i, t);
-                    if (nok && m < p.M) *reinterpret_cast<u32x4*>(dst_ptr(i, t, m)) = v2[t];
-                }
+                for (int t = 0; t < 2; ++t) store_lin(i, t, v2[t]);
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(priv + frow_e * 256 +
-                                              ((((j >> 1) * 8 + fq_e * 2 + (j & 1)) ^ (frow_e & 15)) << 4)) = acc[i][j];
-                // lanes exchange data through LDS inside one wave: the hardware runs a wave's DS instructions in order, the
-                // fences keep the COMPILER from moving a lane's accesses across the hand-over (no instruction is emitted)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_fence();
                 f32x4 a2[2], b2[2], pa2[2], pb2[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -745,15 +791,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         pb2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c2 * 2 + 1) ^ (row & 15)) << 4));
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_fence();
+                if (i + 1 < 8) stage_write(i + 1);
                 float stat_s1[2] = {0.f, 0.f}, stat_s2[2] = {0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int m = row_of(i, t);
                     const f32x4 a = a2[t], b = b2[t];
-                    if (nok && m < p.M) {
+                    if (LINEAR || (nok && m < p.M)) {          // LINEAR: every lane computes, the descriptor drops what does not exist
                         float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                         if (HAS_AUX) {
                             const u32x4 w = aux[i % (AH + 1)][t];
@@ -804,39 +849,50 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             // folded norm, producer side: (sum, sum of squares) of this row's 64 ROUNDED outputs — 8 per lane,
                             // the 8 lanes of the row by DPP (quad_perm xor 1, xor 2, row_half_mirror) — one float2 per row and strip
                             const u32x4 pk = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                            // on the packed pairs (v_dot2: exact products, fp32 accumulation): 2 instructions per pair where
+                            // unpack + add + two fma took 5
+                            constexpr unsigned int ONES2 = (unsigned int)H16_ONE * 0x10001u;
                             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float lo = unpk_lo(pk[e]), hi = unpk_hi(pk[e]);
-                                s1 += lo + hi;
-                                s2 = __builtin_fmaf(lo, lo, s2);
-                                s2 = __builtin_fmaf(hi, hi, s2);
+                                s1 = dot2_acc(pk[e], ONES2, s1);
+                                s2 = dot2_acc(pk[e], pk[e], s2);
                             }
-                            *reinterpret_cast<u32x4*>(dst_ptr(i, t, m)) = pk;
+                            store_lin(i, t, pk);
                             stat_s1[t] = s1;
                             stat_s2[t] = s2;
+                        } else if (LINEAR) {
+                            store_lin(i, t, u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])});
                         } else {
                             st8(dst_ptr(i, t, m), o);
                         }
                     }
                 }
                 if (STATS_EPI && p.row_stats) {        // all lanes here: columns past N and rows past M contributed 0
-                    auto dpp_add = [](float v, auto ctrl) {
-                        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
-                                                                                         0xf, 0xf, true));
-                    };
+                    // the 8 lanes of a row: lane ^ 1, lane ^ 2 (quad_perm), then the other quad (row_half_mirror) — v_add_f32_dpp
+                    // with the permuted operand in the add itself (update_dpp + add compiled to a v_mov_b32_dpp and an add each).
+                    // Hand-placed: a DPP operand written by the previous VALU instruction needs two wait states, which the four
+                    // interleaved chains provide from the second stage on and the s_nop in front of the first.
+                    asm volatile(
+                        "s_nop 1\n\t"
+                        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf"
+                        : "+v"(stat_s1[0]), "+v"(stat_s2[0]), "+v"(stat_s1[1]), "+v"(stat_s2[1]));
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        float s1 = stat_s1[t], s2 = stat_s2[t];
-                        s1 = dpp_add(s1, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]: lane ^ 1
-                        s2 = dpp_add(s2, std::integral_constant<int, 0xB1>{});
-                        s1 = dpp_add(s1, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]: lane ^ 2
-                        s2 = dpp_add(s2, std::integral_constant<int, 0x4E>{});
-                        s1 = dpp_add(s1, std::integral_constant<int, 0x141>{});      // row_half_mirror: the other quad of the 8 lanes
-                        s2 = dpp_add(s2, std::integral_constant<int, 0x141>{});
-                        const int m = row_of(i, t);
-                        if (ch == 0 && m < p.M && n0 + wn * 64 < p.N)
-                            reinterpret_cast<float2*>(p.row_stats)[(int64_t)m * ((p.N + 63) >> 6) + ((n0 >> 6) + wn)] = make_float2(s1, s2);
+                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(stat_s1[t]), __float_as_uint(stat_s2[t])}, rsS,
+                                                              (int)(offS + (unsigned)(i * 16 + t * 8) * st2), 0, 0);
                     }
                 }
             }
