@@ -1067,7 +1067,11 @@ FULL_DEPTH_8B_F32_TOL = 2e-4
 # worst of 32 steps 7.7e-2 ... 8.0e-2 across builds that differ only in an fp32 summation order (bias as the accumulator
 # start instead of an epilogue add): bound = the worst measured value + 10 %
 FULL_DEPTH_8B_BF16_REL_L2 = 8.8e-2
-FULL_DEPTH_8B_BF16_AGREE = 0.935      # measured 0.969 (31 of 32 steps; round 5 build)
+# 32 teacher-forced steps of ONE sequence: the statistic moves in steps of 1 / 32 and every build that changes an fp32 summation
+# order re-rolls the near-ties (f32 margin of the disagreeing steps: 1.7e-2 against a max |dlogit| of 0.35). Measured 0.875 (round 4),
+# 0.969 (round 5 before the epilogue's dot2 row statistics / line-form GELU table), 0.875 (after): floor = the lowest measured value
+# - 2 points. What a disagreeing step may look like is pinned separately just below (its margin < 2 x the largest logit error).
+FULL_DEPTH_8B_BF16_AGREE = 0.855
 
 
 def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
@@ -1116,7 +1120,7 @@ def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     assert max(rel) < FULL_DEPTH_8B_BF16_REL_L2, max(rel)
     for j in (~agree).nonzero().flatten().tolist():
         assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
-    assert rate >= FULL_DEPTH_8B_BF16_AGREE, rate          # measured 0.875; a regression in the head_dim 96 / 128 kernels must not hide below it
+    assert rate >= FULL_DEPTH_8B_BF16_AGREE, rate          # a regression in the head_dim 96 / 128 kernels must not hide below it
     free_g = m16.generate(**sb, max_new_tokens=8)
     free_e = m16.generate(**sb, max_new_tokens=8, use_graph=False)
     assert torch.equal(free_g.sequences, free_e.sequences)
