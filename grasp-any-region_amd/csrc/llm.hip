@@ -4,6 +4,7 @@
 //                  operand with gfx950's transposing LDS read)
 //   embed_lookup   embedding rows of the just-sampled tokens
 //   argmax         greedy sampling with first-index tie break; writes into the device-side token matrix
+//   sample         do_sample = True: temperature / top-k / top-p warpers + one Philox draw per row and step
 #include "common.h"
 
 // Column of natural dim d0 (first element of an 8-wide slice) inside a q / k head whose rows of W — and therefore whose columns
@@ -261,6 +262,276 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sampling (do_sample = True): HF's warpers in their order — temperature, top-k, top-p — then one draw from what is left
+// (transformers TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper + torch.multinomial in GenerationMixin._sample;
+// the reference forwards the caller's GenerationConfig, modeling_gar.py:418-426). One 1024-thread workgroup per row, the row read
+// ~12 times out of L2 (128 k logits: tens of microseconds); no sort:
+//   z = logit / T (fp32 division), ordered by an order-preserving 32-bit key;
+//   top-k: the k-th largest key by a 4 x 8-bit radix descent over COUNTS; keep key >= it (ties at the k-th value stay, as
+//          `scores < topk(scores, k)[0][..., -1]` removes strictly smaller ones only);
+//   top-p: a token stays iff the probability mass of the strictly larger keys is < top_p (HF removes ascending-cumsum <= 1 - top_p:
+//          the same set up to ties, which stay or go together here) — the smallest such key by the same descent over MASS;
+//   draw: u = 24 random bits of Philox4x32-10(key = seed, counter = (step, row)) / 2^24; the token is the first index (in VOCABULARY
+//          order) whose running sum of kept exp(z - max) exceeds u x their total. Deterministic: per-wave histograms merged in wave
+//          order, fixed-shape scans — the same (logits, seed, step, row) always give the same token; oracle/sampling.py restates it.
+// ---------------------------------------------------------------------------------------------------------------
+#define SMP_THREADS 1024
+#define SMP_WAVES (SMP_THREADS / 64)
+
+__device__ __forceinline__ unsigned int smp_key(float z) {           // larger z <-> larger key; -0 and +0 differ (harmless), NaN sorts high
+    const unsigned int u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned int smp_mulhi(unsigned int a, unsigned int b) { return __umulhi(a, b); }
+
+// Philox4x32-10 (Salmon et al. 2011), first output word
+__device__ __forceinline__ unsigned int philox_first(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0,
+                                                     unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned int hi0 = smp_mulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned int hi1 = smp_mulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned int n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* __restrict__ logits, int64_t ld, int V,
+                                                             int64_t* __restrict__ out_tokens, int64_t out_stride,
+                                                             const int32_t* __restrict__ step_dev, int64_t* __restrict__ cur_tokens,
+                                                             const float* __restrict__ params, const int64_t* __restrict__ seed_dev,
+                                                             const int64_t* __restrict__ eos_ids, int n_eos,
+                                                             int32_t* __restrict__ finished, int32_t* __restrict__ done_count) {
+    __shared__ float hist_f[SMP_WAVES][256];        // per-wave mass histograms (merged in wave order: deterministic)
+    __shared__ int hist_i[256];
+    __shared__ float red_f[SMP_WAVES];
+    __shared__ float scan_f[SMP_THREADS];
+    __shared__ unsigned int sh_u[4];
+    __shared__ float sh_f[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* row = logits + (int64_t)b * ld;
+    const float temperature = params[0], top_p = params[1];
+    const int top_k = (int)params[2];
+    const float inv_guard = temperature > 0.f ? temperature : 1.0f;
+    auto zof = [&](int i) { return DT<T>::ld(row + i) / inv_guard; };
+    auto block_sum = [&](float v) -> float {        // fixed shape: xor tree inside a wave, waves in order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if (lane == 0) red_f[wave] = v;
+        __syncthreads();
+        float t = 0.f;
+        for (int w = 0; w < SMP_WAVES; ++w) t += red_f[w];
+        return t;
+    };
+    // ---- max
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += SMP_THREADS) mx = fmaxf(mx, zof(i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    for (int w = 1; w < SMP_WAVES; ++w) mx = fmaxf(mx, red_f[w]);
+    __syncthreads();
+    // ---- top-k: the k-th largest key
+    unsigned int key_lo = 0u;                       // keep key >= key_lo
+    if (top_k > 0 && top_k < V) {
+        unsigned int prefix = 0u;
+        int want = top_k;                           // rank (from the top) still to be found inside the current prefix
+        for (int level = 3; level >= 0; --level) {
+            const int sh = level * 8;
+            const unsigned int pmask = level == 3 ? 0u : (0xffffffffu << (sh + 8));
+            for (int i = tid; i < 256; i += SMP_THREADS) hist_i[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < V; i += SMP_THREADS) {
+                const unsigned int k = smp_key(zof(i));
+                if ((k & pmask) == prefix) atomicAdd(&hist_i[(k >> sh) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int bsel = 0, acc = 0;
+                for (int q = 255; q >= 0; --q) {
+                    if (acc + hist_i[q] >= want) { bsel = q; break; }
+                    acc += hist_i[q];
+                }
+                sh_u[0] = (unsigned int)bsel;
+                sh_u[1] = (unsigned int)(want - acc);
+            }
+            __syncthreads();
+            prefix |= sh_u[0] << sh;
+            want = (int)sh_u[1];
+            __syncthreads();
+        }
+        key_lo = prefix;
+    }
+    // ---- mass of what top-k left
+    float part = 0.f;
+    for (int i = tid; i < V; i += SMP_THREADS) {
+        const float z = zof(i);
+        part += smp_key(z) >= key_lo ? __expf(z - mx) : 0.f;
+    }
+    const float Z1 = block_sum(part);
+    // ---- top-p: the smallest key whose strictly-larger keys hold less than top_p of the mass
+    if (top_p < 1.0f) {
+        const float lim = top_p * Z1;
+        unsigned int prefix = 0u;
+        float above = 0.f;
+        for (int level = 3; level >= 0; --level) {
+            const int sh = level * 8;
+            const unsigned int pmask = level == 3 ? 0u : (0xffffffffu << (sh + 8));
+            for (int i = tid; i < SMP_WAVES * 256; i += SMP_THREADS) (&hist_f[0][0])[i] = 0.f;
+            for (int i = tid; i < 256; i += SMP_THREADS) hist_i[i] = 0;
+            __syncthreads();
+            for (int i0 = wave * 64; i0 < V; i0 += SMP_THREADS) {          // a wave's lanes add in lane order inside one DS instruction
+                const int i = i0 + lane;
+                if (i < V) {
+                    const float z = zof(i);
+                    const unsigned int k = smp_key(z);
+                    if (k >= key_lo && (k & pmask) == prefix) {
+                        atomicAdd(&hist_f[wave][(k >> sh) & 255u], __expf(z - mx));
+                        atomicAdd(&hist_i[(k >> sh) & 255u], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 256) {
+                float t = 0.f;
+                for (int w = 0; w < SMP_WAVES; ++w) t += hist_f[w][tid];
+                scan_f[tid] = t;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                // lowest non-empty bucket whose mass-above is still < lim (the top bucket always qualifies: above = 0 at level 3)
+                int bsel = -1;
+                float run = above, run_sel = above;
+                for (int q = 255; q >= 0; --q) {
+                    if (hist_i[q] > 0) {
+                        if (run < lim || bsel < 0) { bsel = q; run_sel = run; }
+                        else break;
+                    }
+                    run += scan_f[q];
+                }
+                sh_u[0] = (unsigned int)max(bsel, 0);
+                sh_f[0] = run_sel;
+            }
+            __syncthreads();
+            prefix |= sh_u[0] << sh;
+            above = sh_f[0];
+            __syncthreads();
+        }
+        key_lo = max(key_lo, prefix);
+    }
+    // ---- draw: contiguous chunks of the vocabulary per thread, exclusive scan of the chunk sums, the owning thread walks its chunk
+    const int per = (V + SMP_THREADS - 1) / SMP_THREADS;
+    const int c0 = tid * per, c1 = min(V, c0 + per);
+    float csum = 0.f;
+    for (int i = c0; i < c1; ++i) {
+        const float z = zof(i);
+        csum += smp_key(z) >= key_lo ? __expf(z - mx) : 0.f;
+    }
+    scan_f[tid] = csum;
+    __syncthreads();
+    if (tid < SMP_WAVES) {                          // 16 segment sums of 64 chunks each, sequential: a fixed order
+        float t = 0.f;
+        for (int j = 0; j < 64; ++j) t += scan_f[tid * 64 + j];
+        red_f[tid] = t;
+    }
+    __syncthreads();
+    const int step = step_dev ? step_dev[0] : 0;
+    if (tid == 0) {
+        float Z2 = 0.f;
+        for (int w = 0; w < SMP_WAVES; ++w) Z2 += red_f[w];
+        const unsigned long long seed = (unsigned long long)seed_dev[0];
+        const unsigned int r = philox_first((unsigned int)step, (unsigned int)b, 0u, 0u, (unsigned int)seed, (unsigned int)(seed >> 32));
+        const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        const float target = u * Z2;
+        // segment, then chunk, then (below) element: running sums in the same fixed order
+        float run = 0.f;
+        int seg = SMP_WAVES - 1;
+        for (int w = 0; w < SMP_WAVES; ++w) {
+            if (run + red_f[w] > target) { seg = w; break; }
+            run += red_f[w];
+        }
+        if (seg == SMP_WAVES - 1 && !(run + red_f[seg] > target)) {       // rounding at the very end: fall back to the whole last segment
+            run = 0.f;
+            for (int w = 0; w < seg; ++w) run += red_f[w];
+        }
+        int ch = seg * 64 + 63, lastnz = -1;
+        float run_nz = run;
+        bool found = false;
+        for (int j = 0; j < 64; ++j) {
+            const float cs = scan_f[seg * 64 + j];
+            if (run + cs > target) { ch = seg * 64 + j; found = true; break; }
+            if (cs > 0.f) { lastnz = seg * 64 + j; run_nz = run; }
+            run += cs;
+        }
+        if (!found && lastnz >= 0) {      // the chunk-by-chunk sum rounded below the segment sum: the segment's last kept element
+            ch = lastnz;
+            run = run_nz;
+            found = true;
+        }
+        sh_u[0] = (unsigned int)ch;
+        sh_u[1] = found ? 1u : 0u;
+        sh_f[0] = run;
+        sh_f[1] = target;
+    }
+    __syncthreads();
+    if (tid == (int)sh_u[0] || (!sh_u[1] && tid == 0)) {
+        int tok = -1;
+        if (sh_u[1] && tid == (int)sh_u[0]) {
+            float run = sh_f[0];
+            const float target = sh_f[1];
+            for (int i = c0; i < c1; ++i) {
+                const float z = zof(i);
+                if (smp_key(z) >= key_lo) {
+                    run += __expf(z - mx);
+                    tok = i;                               // the last kept index seen: the answer if rounding leaves run == target
+                    if (run > target) break;
+                }
+            }
+        }
+        if (tok < 0 && tid == 0) {                         // nothing exceeded the target (u x total rounded up to the total): last kept index
+            for (int i = V - 1; i >= 0; --i)
+                if (smp_key(zof(i)) >= key_lo) { tok = i; break; }
+        }
+        if (tok >= 0) {
+            if (out_tokens) out_tokens[(int64_t)b * out_stride + step] = tok;
+            if (cur_tokens) cur_tokens[b] = tok;
+            if (finished && eos_ids && finished[b] < 0) {
+                bool hit = false;
+                for (int e = 0; e < n_eos; ++e) hit |= (eos_ids[e] == (int64_t)tok);
+                if (hit) {
+                    finished[b] = step;
+                    if (done_count) atomicAdd(done_count, 1);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int gar_sample(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
+                          const int32_t* step_dev, int64_t* cur_tokens, const float* params_dev, const int64_t* seed_dev,
+                          const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream) {
+    GAR_CHECK_ARG(logits && params_dev && seed_dev && B > 0 && V > 0 && (out_tokens || cur_tokens), "sample: bad args");
+    GAR_CHECK_ARG(n_eos >= 0 && (n_eos == 0 || eos_ids) && (!finished || eos_ids), "sample: eos_ids / finished");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GAR_BF16)
+        hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(B), dim3(SMP_THREADS), 0, s, (const bf16_t*)logits, ld, V, out_tokens, out_stride,
+                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count);
+    else
+        hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(SMP_THREADS), 0, s, (const float*)logits, ld, V, out_tokens, out_stride,
+                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count);
+    GAR_CHECK_LAUNCH();
+    return GAR_OK;
 }
 
 extern "C" int64_t gar_argmax_workspace(int B, int V) {

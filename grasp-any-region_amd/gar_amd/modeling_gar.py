@@ -86,6 +86,30 @@ def _refuse_non_greedy(get):
                                f"and is refused rather than ignored)")
 
 
+def _sampling_options(get):
+    """(temperature, top_p, top_k) of a do_sample = True request, with HF's defaults (GenerationConfig: temperature 1.0, top_k 50,
+    top_p 1.0) and HF's argument checks (TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper). The warpers that are not
+    built (min_p, typical_p, epsilon / eta cutoff) are refused when they would act."""
+    for name, neutral in (("min_p", (None, 0, 0.0)), ("typical_p", (None, 1, 1.0)), ("epsilon_cutoff", (None, 0, 0.0)),
+                          ("eta_cutoff", (None, 0, 0.0))):
+        v = get(name)
+        if not any((v is n) or (n is not None and not isinstance(v, bool) and v == n) for n in neutral):
+            raise hip.GarError(f"sampling option {name}={v!r} is not implemented (temperature, top_k and top_p are)")
+    temperature = get("temperature", 1.0)
+    temperature = 1.0 if temperature is None else float(temperature)
+    if not temperature > 0:
+        raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
+    top_k = get("top_k", 50)
+    top_k = 0 if top_k is None else int(top_k)
+    if top_k < 0:
+        raise ValueError(f"`top_k` has to be a non-negative integer (0 = off), but is {top_k}")
+    top_p = get("top_p", 1.0)
+    top_p = 1.0 if top_p is None else float(top_p)
+    if not 0 < top_p <= 1.0:
+        raise ValueError(f"`top_p` has to be a float > 0 and <= 1, but is {top_p}")
+    return temperature, top_p, top_k
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -902,6 +926,10 @@ class GARModel:
             eos_ids=self._buf(key, "eos_ids", (self.MAX_EOS_IDS,), torch.int64),
             finished=self._buf(key, "finished", (B,), torch.int32),
             done_count=self._buf(key, "done_count", (1,), torch.int32, zero=True),
+            # do_sample = True (gar_sample): [temperature, top_p, top_k] and the Philox key of the request, read by the captured step
+            sample_params=self._buf(key, "sample_params", (4,), torch.float32, zero=True),
+            sample_seed=self._buf(key, "sample_seed", (1,), torch.int64, zero=True),
+            sampling=False,
             slot=slot,
         )
         return key, st
@@ -1042,8 +1070,13 @@ class GARModel:
         else:
             ops.rmsnorm(last_rows, self.final_norm, t.rms_norm_eps, out=xn)
             ops.gemm(xn, self.lm_head, logits)
-        ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws, eos_ids=st["eos_ids"],
-                   finished=st["finished"] if finished is None else finished, done_count=st["done_count"])
+        fin = st["finished"] if finished is None else finished
+        if st.get("sampling"):
+            ops.sample(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, st["sample_params"], st["sample_seed"],
+                       eos_ids=st["eos_ids"], finished=fin, done_count=st["done_count"])
+        else:
+            ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws, eos_ids=st["eos_ids"],
+                       finished=fin, done_count=st["done_count"])
         return logits
 
     def _decode_step(self, st, B: int, Smax: int, out_tokens):
@@ -1181,8 +1214,10 @@ class GARModel:
                        max_new_tokens: Optional[int] = None, eos_token_id=None, use_graph: bool = True, validate: bool = True,
                        return_logits: bool = False, sync_every: int = 16, feature_replay_video: bool = False,
                        video_frame_tokens: Optional[Sequence[int]] = None, forced_tokens: Optional[torch.Tensor] = None,
-                       state_slot: int = 0, **generate_kwargs) -> "_PendingGeneration":
-        """Greedy region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428).
+                       state_slot: int = 0, seed: Optional[int] = None, **generate_kwargs) -> "_PendingGeneration":
+        """Region captioning, reference semantics of GARModel.generate (modeling_gar.py:295-428): greedy search, or — with
+        ``do_sample=True`` in the generation config — temperature / top-k / top-p sampling on the device (``seed``: the Philox key of
+        the request; None draws one from torch's global generator).
 
         B = input_ids.shape[0] samples are processed together (the reference handles B=1 per call; its loop over
         ``batch_idx`` is kept). ``pixel_values`` / ``global_mask_values``: [B*(T+1), 3, H, W] (flattened tiles as the
@@ -1192,11 +1227,12 @@ class GARModel:
         every step, but the token fed back as step j's input is ``forced_tokens[:, j]``, so two models (bf16 vs f32) can be
         compared on identical contexts over a whole caption."""
         gc = generation_config
+        sampling = None
         if gc is not None:
             get = (lambda k, d=None: gc.get(k, d)) if isinstance(gc, dict) else (lambda k, d=None: getattr(gc, k, d))
-            if get("do_sample", False):
-                raise hip.GarError("only greedy decoding (do_sample=False) is implemented, as the reference's callers use")
             _refuse_non_greedy(get)
+            if get("do_sample", False):
+                sampling = _sampling_options(get)
             max_new_tokens = max_new_tokens or get("max_new_tokens")
             if eos_token_id is None:
                 eos_token_id = get("eos_token_id")
@@ -1248,6 +1284,12 @@ class GARModel:
         st["eos_ids"].fill_(-1)
         if eos_list and eos_on_device:
             st["eos_ids"][:len(eos_list)].copy_(torch.tensor(eos_list, dtype=torch.int64).pin_memory(), non_blocking=True)
+        st["sampling"] = sampling is not None
+        if sampling is not None:
+            if seed is None:          # HF draws from torch's global generator: so does the key of this request (torch.manual_seed reproduces it)
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+            st["sample_params"].copy_(torch.tensor([sampling[0], sampling[1], float(sampling[2]), 0.0]).pin_memory(), non_blocking=True)
+            st["sample_seed"].copy_(torch.tensor([int(seed)], dtype=torch.int64).pin_memory(), non_blocking=True)
         V = cfg.mllm_config.text_config.vocab_size
         tiles = 0
         if pixel_values is not None:
@@ -1395,7 +1437,7 @@ class GARModel:
     def _decode_graph(self, st, B, Smax, out_tokens, skey):
         """(graph, logits buffer of the captured step). out_tokens is a [:, :n] slice of the state's [B, Smax] buffer:
         pointer and row stride depend on the state only, so one graph serves every max_new_tokens of the bucket."""
-        gkey = (skey, out_tokens.data_ptr(), out_tokens.stride(0))
+        gkey = (skey, out_tokens.data_ptr(), out_tokens.stride(0), bool(st.get("sampling")))
         g = self._graphs.get(gkey)
         if g is None:
             # what the warm-up step writes and the loop reads: counters, the current tokens, the stopping-criterion latches

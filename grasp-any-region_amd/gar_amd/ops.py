@@ -550,6 +550,21 @@ def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace, e
                            0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), stream()), "gar_argmax")
 
 
+def sample(logits, V, out_tokens, out_stride, step_dev, cur_tokens, params, seed, eos_ids=None, finished=None, done_count=None):
+    """do_sample = True: temperature / top-k / top-p + one Philox draw per row (``gar_sample``). ``params`` float32 [3] (device):
+    temperature, top_p, top_k; ``seed`` int64 [1] (device). Token placement and eos latches as :func:`argmax`."""
+    B = logits.shape[0]
+    assert params.dtype == torch.float32 and params.numel() >= 3 and params.is_contiguous()
+    assert seed.dtype == torch.int64 and seed.numel() >= 1
+    assert eos_ids is None or (eos_ids.dtype == torch.int64 and eos_ids.is_contiguous())
+    assert finished is None or (eos_ids is not None and finished.dtype == torch.int32 and finished.is_contiguous()
+                                and finished.numel() == B)
+    check(lib(logits.dtype).gar_sample(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
+                                       ptr(step_dev), ptr(cur_tokens), ptr(params), ptr(seed), ptr(eos_ids),
+                                       0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), stream()),
+          "gar_sample")
+
+
 def argmax_workspace(B, V) -> int:
     return int(lib().gar_argmax_workspace(B, V))
 

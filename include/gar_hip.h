@@ -38,7 +38,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 12
+#define GAR_ABI_VERSION 13
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -373,6 +373,16 @@ int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t*
                 * number of latched rows). All three may be NULL (n_eos = 0): plain argmax. */
                const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream);
 int64_t gar_argmax_workspace(int B, int V);
+/* do_sample = True (ABI 13): HF's TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> one multinomial draw
+ * (transformers GenerationMixin._sample; the reference forwards the caller's GenerationConfig, modeling_gar.py:418-426), on the
+ * device and hipGraph-replayable: params_dev float [3] = {temperature > 0, top_p in (0, 1] (1 = off), top_k (0 or >= V = off)},
+ * seed_dev int64 [1]; the draw of (row b, step step_dev[0]) is Philox4x32-10(key = seed, counter = (step, b, 0, 0)), 24 bits ->
+ * u in [0, 1), and the token is the first index in vocabulary order whose running sum of kept exp((logit - max) / T) exceeds
+ * u x their total (oracle/sampling.py restates kernel and RNG; tests/test_oracle_goldens.py pins its kept set against
+ * transformers' warpers). Token placement and the eos latches are gar_argmax's. */
+int gar_sample(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
+               const int32_t* step_dev, int64_t* cur_tokens, const float* params_dev, const int64_t* seed_dev,
+               const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream);
 int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 
 /* The input checks of the reference's generate() without a host sync: image-token count vs feature rows (ValueError,
