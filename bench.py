@@ -92,6 +92,9 @@ def parse(argv=None):
                          "admitted into the running decode loop)")
     ap.add_argument("--eos-mix-tokens", type=int, default=256, help="--eos-mix: max_new_tokens (the reference's callers use 1024)")
     ap.add_argument("--eos-mix-batches", type=int, default=3, help="--eos-mix: queue length in units of --batch regions")
+    ap.add_argument("--eos-mix-admit-min", type=int, default=0,
+                    help="--eos-mix: free rows the continuous batcher waits for before it runs a prompt phase (0 = its default, slots / 4)")
+    ap.add_argument("--eos-mix-poll", type=int, default=8, help="--eos-mix: decode steps between two polls of the finished latches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args(argv)
@@ -278,7 +281,8 @@ def eos_mix(args, model, make_batch, B, S, tiles, rt):
         return caps, steps
 
     def continuous_leg():
-        cb = ContinuousBatcher(model, slots=B, max_new_tokens=NM, eos_token_id=eos, poll_every=8, validate=False)
+        cb = ContinuousBatcher(model, slots=B, max_new_tokens=NM, eos_token_id=eos, poll_every=args.eos_mix_poll,
+                               admit_min=args.eos_mix_admit_min or None, validate=False)
         tickets = [cb.submit(r) for r in regions]
         res = cb.flush()
         return [res[t] for t in tickets], cb.stats

@@ -196,8 +196,9 @@ def test_reference_generate_prologue_through_the_facade(tiny, dt):
 
 
 def test_generation_options_that_would_change_greedy_tokens_are_refused(tiny):
-    """modeling_gar.py:418-426 forwards any GenerationConfig to HF; here only greedy search exists: beams / penalties raise
-    (they used to be ignored), sampling-only knobs without do_sample are accepted as HF accepts them."""
+    """modeling_gar.py:418-426 forwards any GenerationConfig to HF; here greedy search and temperature / top-k / top-p sampling
+    exist (tests/test_gpu_sampling.py): beams / penalties / the other warpers raise (they used to be ignored), sampling-only knobs
+    without do_sample are accepted as HF accepts them."""
     from gar_amd import hip
     from gar_amd.modeling_gar import GARModel
     cfg, W, proc = tiny
@@ -207,7 +208,7 @@ def test_generation_options_that_would_change_greedy_tokens_are_refused(tiny):
                                                   temperature=0.7, top_p=0.9))
     assert base.sequences.shape == (1, 3)
     for bad in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(no_repeat_ngram_size=2), dict(min_new_tokens=5),
-                dict(bad_words_ids=[[3]]), dict(do_sample=True)):
+                dict(bad_words_ids=[[3]]), dict(do_sample=True, min_p=0.1), dict(do_sample=True, num_beams=2)):
         with pytest.raises(hip.GarError):
             m.generate(**s, generation_config=dict(max_new_tokens=3, **bad))
 
