@@ -644,13 +644,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         bf16_t* const qkv_P0 = QKV ? (bf16_t*)(part == 0 ? p.qkv_q : (part == 1 ? p.qkv_k : p.qkv_v)) +
                                          ((int64_t)tile_w * p.qkv_heads + qh) * p.qkv_tokens_pad * p.qkv_head_dim + qd
                                    : nullptr;
+        // Row 0 of the compact table is the identity (sin, cos) = (0, 1) (ABI 14); token tok reads row max(tok - prefix + 1, 0), so the
+        // un-rotated prefix (cls) rows take the identity by INDEX, and a lane that rotates nothing (v columns, columns past N) by a row
+        // pitch of 0 — no per-element selects. One address per slot, both 16-byte halves off it.
         const float* const sc_P0 = QKV ? p.qkv_sin + (rot_lane ? qd : 0) : nullptr;
-        auto sc_load = [&](int i, int t, int half) -> u32x4 {
+        const unsigned sc_pitch = rot_lane ? (unsigned)p.qkv_head_dim : 0u;
+        auto sc_load = [&](int i, int t, u32x4 (&dst)[2]) {
             const int m = min(row_of(i, t), p.M - 1);
             int tile, tok;
             split_row(m, tile, tok);
-            const int rt = max(tok - p.qkv_prefix, 0);
-            return *reinterpret_cast<const u32x4*>(sc_P0 + rt * p.qkv_head_dim + half * 4);
+            const unsigned rt = (unsigned)max(tok - p.qkv_prefix + 1, 0);
+            const float* ptr = sc_P0 + __umul24(rt, sc_pitch);
+            dst[0] = *reinterpret_cast<const u32x4*>(ptr);
+            dst[1] = *reinterpret_cast<const u32x4*>(ptr + 4);
         };
         // QKV_ROPE_LLM (HF Llama): half-split RoPE — the partner of dim d is d +- hd/2, which the W row order (gar_hip.h) puts
         // 32 columns away in the SAME 64-column strip: lanes (rr, c) and (rr, c + 4), c < 4, both read x1 = columns 8c.. and
@@ -700,9 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         u32x4 sc[2][2][2];
         if (QKV) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) sc[0][t][hf] = sc_load(0, t, hf);
+            for (int t = 0; t < 2; ++t) sc_load(0, t, sc[0][t]);
         }
 #ifndef PP_AUX_AHEAD      /* 16-row steps the row-dependent loads run ahead of their use (ring of PP_AUX_AHEAD + 1 slots) */
 #define PP_AUX_AHEAD 2
@@ -757,9 +761,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             }
             if (QKV && i + 1 < 8) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) sc[(i + 1) & 1][t][hf] = sc_load(i + 1, t, hf);
+                for (int t = 0; t < 2; ++t) sc_load(i + 1, t, sc[(i + 1) & 1][t]);
             }
             if (QKVL && l_rot && i + 1 < 8) l_load(i + 1, (i + 1) & 1);
             if (DIRECT) {
@@ -833,15 +835,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                             int tile, tok;
                             split_row(m, tile, tok);
                             if (any_rot) {          // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs; q also carries its scale
-                                const bool rot = rot_lane && tok >= p.qkv_prefix;
+                                // three packed instructions per pair: (sn, cs) * q;  t = (x1 sn, x0 sn);  (x0 cs - t.lo, x1 cs + t.hi)
+                                // — the products and their roundings of x0 * cs + (-x1) * sn / x1 * cs + x0 * sn. Pinned: left to
+                                // itself the compiler built both signs of every pair and selected (4 packed + 4 scalar + moves).
+                                typedef float f32v2_e __attribute__((ext_vector_type(2)));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const u32x4 w = sc[i & 1][t][e >> 1];
-                                    const float sn = (rot ? __uint_as_float(w[(e & 1) * 2]) : 0.0f) * q_mult;
-                                    const float cs = (rot ? __uint_as_float(w[(e & 1) * 2 + 1]) : 1.0f) * q_mult;
-                                    const float x0 = o[2 * e], x1 = o[2 * e + 1];
-                                    o[2 * e] = x0 * cs + (-x1) * sn;
-                                    o[2 * e + 1] = x1 * cs + x0 * sn;
+                                    const f32v2_e scq = f32v2_e{__uint_as_float(w[(e & 1) * 2]), __uint_as_float(w[(e & 1) * 2 + 1])} *
+                                                        f32v2_e{q_mult, q_mult};
+                                    const f32v2_e x = {o[2 * e], o[2 * e + 1]};
+                                    f32v2_e tx, r;
+                                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(tx) : "v"(x), "v"(scq));
+                                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1]"
+                                        : "=v"(r) : "v"(x), "v"(scq), "v"(tx));
+                                    o[2 * e] = r[0];
+                                    o[2 * e + 1] = r[1];
                                 }
                             }
                             st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);

@@ -18,7 +18,7 @@ GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
  EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class GarError(RuntimeError):

@@ -262,7 +262,11 @@ def _compact_sincos(sin: torch.Tensor, cos: torch.Tensor):
     if hit is None:
         ok = (sin.dtype == torch.float32 and cos.dtype == torch.float32 and sin.shape[-1] % 8 == 0 and
               bool(torch.equal(sin[:, 0::2], sin[:, 1::2])) and bool(torch.equal(cos[:, 0::2], cos[:, 1::2])))
-        hit = (torch.stack([sin[:, 0::2], cos[:, 0::2]], dim=-1).contiguous() if ok else False, sin, cos)   # keeps the key's tensors alive
+        if ok:      # row 0 = the identity (sin, cos) = (0, 1): what the un-rotated prefix rows and the v columns read (gar_hip.h, ABI 14)
+            pairs = torch.stack([sin[:, 0::2], cos[:, 0::2]], dim=-1)
+            ident = torch.stack([torch.zeros_like(pairs[:1, :, 0]), torch.ones_like(pairs[:1, :, 1])], dim=-1)
+            pairs = torch.cat([ident, pairs], 0).contiguous()
+        hit = (pairs if ok else False, sin, cos)   # keeps the key's tensors alive
         _SINCOS_CACHE[key] = hit
     return hit[0] if hit[0] is not False else None
 

@@ -38,7 +38,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 13
+#define GAR_ABI_VERSION 14
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -95,8 +95,10 @@ typedef struct gar_gemm_params {
     /* GAR_EPI_QKV_ROPE only */
     void* qkv_q; void* qkv_k;          /* [tiles, heads, qkv_tokens_pad, head_dim]                                   */
     const float* qkv_sin; const float* qkv_cos;   /* [qkv_tokens - qkv_prefix, head_dim]; or qkv_cos == NULL and qkv_sin =   */
-                                                  /* compact (sin, cos) pairs [qkv_tokens - qkv_prefix, head_dim/2][2] when  */
-                                                  /* the tables repeat each value for both elements of a rotated pair (timm) */
+                                                  /* compact (sin, cos) pairs [1 + qkv_tokens - qkv_prefix, head_dim/2][2]   */
+                                                  /* when the tables repeat each value for both elements of a rotated pair   */
+                                                  /* (timm); ABI 14: row 0 is the identity (0, 1) — what the prefix rows and */
+                                                  /* the v columns read — and token t's angles are row t - qkv_prefix + 1    */
     int32_t qkv_heads, qkv_head_dim, qkv_tokens, qkv_tokens_pad, qkv_prefix;
     float qkv_q_scale;
     /* Split-K for the decode GEMMs (bf16, M <= 64, GAR_EPI_NONE, no norm_w): with split_k > 1 the K range is cut into
