@@ -654,7 +654,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             int tile, tok;
             split_row(m, tile, tok);
             const unsigned rt = (unsigned)max(tok - p.qkv_prefix + 1, 0);
+#ifdef PP_QKV_NOTABLE     /* diagnostic build: every slot reads the identity row (one L1-resident line) */
+            const float* ptr = sc_P0 + __umul24(rt, 0u);
+#else
             const float* ptr = sc_P0 + __umul24(rt, sc_pitch);
+#endif
             dst[0] = *reinterpret_cast<const u32x4*>(ptr);
             dst[1] = *reinterpret_cast<const u32x4*>(ptr + 4);
         };
@@ -853,6 +857,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                     o[2 * e + 1] = r[1];
                                 }
                             }
+#ifdef PP_QKV_NOSTORE     /* diagnostic build: the rotated rows are computed and never stored */
+                            if (p.tokens_in == -12345)
+#endif
                             st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
                         } else if (STATS_EPI && p.row_stats) {
                             // folded norm, producer side: (sum, sum of squares) of this row's 64 ROUNDED outputs — 8 per lane,
