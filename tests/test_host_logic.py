@@ -181,13 +181,15 @@ def test_checkpoint_normalisation_fills_config_and_folds_bias_variants(vision_bi
 
 def test_compact_sincos_table_for_the_fused_rope_epilogue():
     """ops._compact_sincos: (sin, cos)-pair table only when every angle is repeated for both elements of a rotated pair
-    (timm's cat layout); anything else keeps the full tables (the library then takes its general epilogue)."""
+    (timm's cat layout), with the identity row (0, 1) in front that un-rotated rows / columns read (gar_hip.h, ABI 14); anything
+    else keeps the full tables (the library then takes its general epilogue)."""
     from gar_amd import ops
     ang = torch.randn(40, 32)
     sin, cos = ang.sin().repeat_interleave(2, -1).contiguous(), ang.cos().repeat_interleave(2, -1).contiguous()
     sc = ops._compact_sincos(sin, cos)
-    assert sc.shape == (40, 32, 2) and sc.is_contiguous()
-    assert torch.equal(sc[..., 0], ang.sin()) and torch.equal(sc[..., 1], ang.cos())
+    assert sc.shape == (41, 32, 2) and sc.is_contiguous()
+    assert torch.equal(sc[0, :, 0], torch.zeros(32)) and torch.equal(sc[0, :, 1], torch.ones(32))
+    assert torch.equal(sc[1:, :, 0], ang.sin()) and torch.equal(sc[1:, :, 1], ang.cos())
     assert ops._compact_sincos(sin, cos) is sc                              # cached per table pair
     sin2 = sin.clone()
     sin2[3, 5] += 0.25                                                      # pair no longer shares its angle
