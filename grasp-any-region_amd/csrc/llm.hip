@@ -320,8 +320,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* __restrict
     const T* row = logits + (int64_t)b * ld;
     const float temperature = params[0], top_p = params[1];
     const int top_k = (int)params[2];
-    const float inv_guard = temperature > 0.f ? temperature : 1.0f;
-    auto zof = [&](int i) { return DT<T>::ld(row + i) / inv_guard; };
+    const float temp = temperature > 0.f ? temperature : 1.0f;             // (the host refuses temperature <= 0, as HF does)
+    auto zof = [&](int i) { return DT<T>::ld(row + i) / temp; };
     auto block_sum = [&](float v) -> float {        // fixed shape: xor tree inside a wave, waves in order
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
