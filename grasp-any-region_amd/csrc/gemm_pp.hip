@@ -66,10 +66,10 @@
 #define PP_W_AUX 0
 #endif
 #ifndef PP_ST_AUX        /* diagnostic builds: cache-policy bits of the epilogue's output stores / residual loads (1 = sc0, 2 = nt, 16 = sc1) */
-#define PP_ST_AUX 0
+#define PP_ST_AUX 2          /* nt: +0.4 % weighted with the residual loads (profiles/r5_gemm_epilogue_traffic.txt 6) */
 #endif
 #ifndef PP_RES_AUX
-#define PP_RES_AUX 0
+#define PP_RES_AUX 2
 #endif
 template <int AUX = 0>
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int voff, unsigned row_bytes, unsigned base,
@@ -86,6 +86,17 @@ __device__ __forceinline__ void dma1(__amdgpu_buffer_rsrc_t rsrc, int voff, unsi
                                      int wave, int i) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_AS(lds + (i * 8 + wave) * 1024), 16,
                                              voff + (int)(base + (unsigned)(i * 64) * row_bytes), 0, 0, AUX);
+}
+
+// 16-byte output stores of the pointer-addressed epilogues (q / k / v rows, patch-embed): streamed once, read by the
+// NEXT kernel — non-temporal like the buffer stores of the linear epilogues (PP_NT_PTR_STORES=0: plain stores, diagnostic builds)
+#ifndef PP_NT_PTR_STORES
+#define PP_NT_PTR_STORES 1
+#endif
+__device__ __forceinline__ void pp_st8(bf16_t* p, const float (&v)[8]) {
+    const u32x4 w = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    if (PP_NT_PTR_STORES) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = w;
 }
 
 // GELU by table (BIAS_GELU epilogue): the erf GELU of a 256 x 256 tile costs ~46 VALU cycles per element as A&S 7.1.26
@@ -359,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = silu_fast(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r];
                         if (i * 16 + frow < m_lim)
+                            // (plain stores: as non-temporal 8-byte stores — half the lines written in two pieces — this GEMM is 11 % slower)
                             *reinterpret_cast<uint2*>(Cw + ((unsigned)(i * 16 + frow) * ldc2 + col2)) =
                                 make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
                     }
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                                     o[e] = __builtin_fmaf(x2[e], theirs * l_sg, o[e] * mine);
                                 }
                             }
-                            st8(l_P0 + ((tile - tile_w) * l_TS + tok * lHD), o);
+                            pp_st8(l_P0 + ((tile - tile_w) * l_TS + tok * lHD), o);
                         } else if (QKV) {
                             int tile, tok;
                             split_row(m, tile, tok);
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #ifdef PP_QKV_NOSTORE     /* diagnostic build: the rotated rows are computed and never stored */
                             if (p.tokens_in == -12345)
 #endif
-                            st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
+                            pp_st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
                         } else if (STATS_EPI && p.row_stats) {
                             // folded norm, producer side: (sum, sum of squares) of this row's 64 ROUNDED outputs — 8 per lane,
                             // the 8 lanes of the row by DPP (quad_perm xor 1, xor 2, row_half_mirror) — one float2 per row and strip
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
                         } else if (LINEAR) {
                             store_lin(i, t, u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])});
                         } else {
-                            st8(dst_ptr(i, t, m), o);
+                            pp_st8(dst_ptr(i, t, m), o);
                         }
                     }
                 }
