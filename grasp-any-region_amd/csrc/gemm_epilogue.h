@@ -132,7 +132,10 @@ __device__ __forceinline__ int tile_group_m(int K, int tiles_n) {
 #ifdef GAR_TILE_GM
     return GAR_TILE_GM;
 #else
-    if (K <= 2048 && tiles_n <= 8) return 8;
+    // round 5 re-sweep on the final epilogues (profiles/r5_gemm_epilogue_traffic.txt 7): the ViT proj (K = 1024, 4 n-tiles) takes 16
+    // m-panels per group (0.795 -> 0.778 ms), Llama's qkv (K = 2048, 12 n-tiles) 8 like o-proj (1.233 -> 1.214 ms)
+    if (K <= 1024 && tiles_n <= 4) return 16;
+    if (K <= 2048 && tiles_n <= 12) return 8;
     return max(1, min(8, 8192 / K));
 #endif
 }
