@@ -20,11 +20,12 @@
 bool gar_attn_bf16_v2_try(const void* Q, const void* K, const void* Vt, void* O, int B, int Hq, int Hkv, int hd, int q_len,
                           int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev, int vrow,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s, int o_rows = 0);
-// attention_v4.hip: the 4-wave persistent kernel (head_dim 64, row-major V, >= 256 query rows): query rows q_row0 .. q_row0 + q_len - 1
-// of sequences of q_total rows; false -> not built for this problem
+#ifdef GAR_ATTN_V4_VARIANT   /* diagnostic build only (tools/attn_v4/: the round-5 4-wave persistent kernel, slower than v2) */
+// query rows q_row0 .. q_row0 + q_len - 1 of sequences of q_total rows; false -> not built for this problem
 bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd, int q_row0,
                           int q_len, int q_total, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s);
+#endif
 
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }
@@ -457,8 +458,9 @@ extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const
         GAR_CHECK_LAUNCH();
         return GAR_OK;
     }
+#ifdef GAR_ATTN_V4_VARIANT
     if (dtype == GAR_BF16 && hd == 64 && q_len >= 256 && !kv_len_dev) {
-        // v4 (attention_v4.hip) walks 256-row Q blocks. A non-causal sequence whose length is a few rows more than a multiple of
+        // v4 (tools/attn_v4/attention_v4.hip) walks 256-row Q blocks. A non-causal sequence whose length is a few rows more than a multiple of
         // 256 — the ViT tile: 1 cls + 1024 patch tokens — gives those first rows to v2 (one q-block with `head` live rows costs
         // what a ninth of the tile costs) and whole blocks to v4, instead of a fifth 256-row block with one live row.
         const int head = (!causal && (q_len % 256) <= 32) ? q_len % 256 : 0;
@@ -473,6 +475,7 @@ extern "C" int gar_attention_vrow(int dtype, const void* Q, const void* K, const
             return GAR_OK;
         }
     }
+#endif
     if (dtype != GAR_BF16 || (hd != 64 && hd != 96 && hd != 128) ||
         !gar_attn_bf16_v2_try(Q, K, V, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, causal, kv_len_dev, 1, kv_start,
                               kv_prefix, s)) {

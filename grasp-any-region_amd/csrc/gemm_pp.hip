@@ -540,393 +540,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
         }
     };
 
-    // Barrier-free per-wave epilogue (none / bias / gelu / residual / LayerScale / pos-embed outputs): every wave turns its
-    // own 128 x 64 strip from MFMA fragments into rows through a PRIVATE 4-KiB piece of the consumed stage — its wave
-    // row's A half, which only that row ever reads — 16 rows at a time, and stores 8 rows x 128 contiguous bytes per
-    // instruction. No workgroup barrier, no cross-wave hand-over: the eight waves run their LDS / ALU / store streams
-    // independently, and wave row 0's un-stagger barrier sits after its first 16 rows instead of in front of idle time.
-    // DIRECT outputs (a function of accumulator and column only) are rounded on the fragments and staged as bf16; the
-    // others are staged in fp32 and finished on the row side, with the row-dependent loads (residual / pos-embed)
-    // issued two 16-row steps ahead: vmcnt retires in order, so a load issued behind a store waits for that store's ack.
-    auto epilogue_wave = [&](char* E) {
-        constexpr bool QKV = EPI == GAR_EPI_QKV_ROPE;       // compact sin/cos table only (qkv_cos == NULL)
-        constexpr bool DIRECT = EPI == GAR_EPI_NONE || EPI == GAR_EPI_BIAS || EPI == GAR_EPI_BIAS_GELU;
-        constexpr bool HAS_AUX = EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES || EPI == GAR_EPI_PATCH_POS;
-        int lane_e = lane, frow_e = frow, fq_e = fq;
-        asm volatile("" : "+v"(lane_e), "+v"(frow_e), "+v"(fq_e));             // see epilogue_lds
-        char* priv = E + wm * PHALF + wn * 4096;
-        const int rr = lane_e >> 3, ch = lane_e & 7;      // row side: rows rr and 8 + rr of a 16-row step, 8 columns ch*8..
-        const int n = n0 + wn * 64 + ch * 8;
-        const bool nok = n < p.N;
-        float gam8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // LayerScale of this lane's row-side columns (the bias is in the accumulators)
-        if (EPI == GAR_EPI_BIAS_SCALE_RES && nok) ld8((const bf16_t*)p.gamma + n, gam8);
-        // destination element offset and row-dependent load of row-side slot (i, t)
-        auto row_of = [&](int i, int t) { return m0 + wm * 128 + i * 16 + t * 8 + rr; };
-        // (image tile, token) of row m for the epilogues that address by token (PATCH_POS, QKV_ROPE). The 128 rows of a
-        // wave's strip are consecutive and span at most two image tiles when a tile has >= 128 tokens: ONE integer division
-        // per strip and a compare / select per row instead of a ~25-instruction division per row (32 per lane and tile —
-        // as many VALU instructions as the rest of the QKV_ROPE epilogue)
-        const int TT = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_QKV_ROPE_LLM) ? p.qkv_tokens
-                                                                                : (EPI == GAR_EPI_PATCH_POS ? p.tokens_in : 1);
-        const int mw = m0 + wm * 128;
-        const int tile_w = (EPI == GAR_EPI_QKV_ROPE || EPI == GAR_EPI_QKV_ROPE_LLM || EPI == GAR_EPI_PATCH_POS) ? mw / TT : 0;
-        const int tok_w = mw - tile_w * TT;
-        auto split_row = [&](int m, int& tile, int& tok) {
-            if (TT >= 128) {
-                tok = tok_w + (m - mw);
-                const bool wrap = tok >= TT;
-                tile = tile_w + (wrap ? 1 : 0);
-                tok -= wrap ? TT : 0;
-            } else {
-                tile = m / TT;
-                tok = m - tile * TT;
-            }
-        };
-        // Addresses of slot (i, t). Linear outputs (everything but PATCH_POS / QKV_ROPE): a WAVE-UNIFORM 64-bit base — row
-        // mw + 16 i + 8 t of C / of the residual, scalar arithmetic — plus this lane's 32-bit byte offset (row rr, column n),
-        // so the store / load takes its `saddr` form: ~2 VALU per slot where the per-lane 64-bit m * ld + n chain took 9.
-        // (the base is per TILE — C + mw * ldc — and the slot's row offset (16 i + 8 t) * ld, < 2^24, joins the lane's
-        // offset in one v_mad_u32_u24: no 64-bit arithmetic per slot, scalar or vector)
-        const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u, n2 = (unsigned)(nok ? n : 0) * 2u;
-        // LINEAR outputs go through buffer descriptors whose base is the strip's first row and whose extent is the rows of
-        // the strip that exist (<= 128): a store to a row past M is dropped and a residual load from one returns 0 by the
-        // descriptor's range check, a lane whose columns lie past N carries an offset no extent reaches — no exec masking,
-        // no clamps and no 64-bit arithmetic per slot; the slot's row offset joins the lane's 32-bit offset in one add
-        // (in the VGPR offset: the range check does not cover the scalar offset operand).
-        constexpr bool LINEAR = EPI != GAR_EPI_PATCH_POS && EPI != GAR_EPI_QKV_ROPE && EPI != GAR_EPI_QKV_ROPE_LLM;
-        constexpr unsigned OFF_NONE = 0x7fff0000u;
-        // (readfirstlane: min / max / med3 have no scalar form, and a descriptor word that lives in a VGPR is treated as
-        // divergent — a waterfall loop around every access)
-        const int rows_here = LINEAR ? __builtin_amdgcn_readfirstlane(max(min(p.M - mw, 128), 0)) : 0;
-        char* const Cw = PP_DIAG_L2STORE ? (char*)p.C + (int64_t)(wm * 128) * p.ldc * 2 - (int64_t)n0 * 2      // diagnostic build: L2-resident stores
-                                         : (char*)p.C + (int64_t)mw * p.ldc * 2;
-#ifdef PP_DROPSTORE   /* diagnostic build: the whole epilogue runs, but the output descriptor's extent is 0 — every store is issued
-                         and dropped by the range check (what the epilogue costs without its write traffic) */
-        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cw, 0, 0, 0x00020000);
-#else
-        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cw, 0, (int)((unsigned)rows_here * ldc2), 0x00020000);
-#endif
-        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((char*)const_cast<void*>(p.residual) + (int64_t)mw * p.ldr * 2), 0,
-#ifdef PP_DROPRES      /* diagnostic build: residual loads answered (with 0) by the range check — no read traffic */
-            0, 0x00020000);
-#else
-            (int)((EPI == GAR_EPI_BIAS_SCALE_RES || EPI == GAR_EPI_RES) ? (unsigned)rows_here * ldr2 : 0u), 0x00020000);
-#endif
-        const unsigned offC = nok ? (unsigned)rr * ldc2 + n2 : OFF_NONE, offR = nok ? (unsigned)rr * ldr2 + n2 : OFF_NONE;
-        // row statistics (float2 per row and 64-column strip): the same scheme, one lane per row
-        const unsigned st2 = (unsigned)((p.N + 63) >> 6) * 8u;
-        const bool stats_on = STATS_EPI && p.row_stats != nullptr && n0 + wn * 64 < p.N;
-        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((char*)p.row_stats + ((int64_t)mw * ((p.N + 63) >> 6) + ((n0 >> 6) + wn)) * 8), 0,
-            (int)(stats_on ? (unsigned)rows_here * st2 : 0u), 0x00020000);
-        const unsigned offS = ch == 0 ? (unsigned)rr * st2 : OFF_NONE;
-        auto store_lin = [&](int i, int t, const u32x4& v) {
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsC, (int)(offC + (unsigned)(i * 16 + t * 8) * ldc2), 0, PP_ST_AUX);
-        };
-        auto dst_ptr = [&](int i, int t, int m) -> bf16_t* {           // PATCH_POS only
-            int tile, tok;
-            split_row(m, tile, tok);
-            return (bf16_t*)p.C + ((int64_t)tile * p.tokens_out + p.token_offset + tok) * p.ldc + n;
-        };
-        auto aux_load = [&](int i, int t) -> u32x4 {        // unconditional so the prefetch ring carries no exec state
-            if (EPI == GAR_EPI_PATCH_POS) {
-                const int m = min(row_of(i, t), p.M - 1), nc = nok ? n : 0;
-                int tile, tk;
-                split_row(m, tile, tk);
-                const int tok = p.token_offset + max(tk, 0);
-                return *reinterpret_cast<const u32x4*>((const bf16_t*)p.pos + (int64_t)tok * p.N + nc);
-            }
-            return __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(offR + (unsigned)(i * 16 + t * 8) * ldr2), 0, PP_RES_AUX);
-        };
-        // QKV_ROPE: this lane's 8 columns are dims qd..qd+7 of head qh of q (part 0), k (1) or v (2); the rotation of row
-        // (token) tok needs the four (sin, cos) pairs of those dims: two 16-byte loads, issued one 16-row step ahead.
-        // Branch-free per slot: ONE destination pointer (q / k / v base chosen per lane, all three head-major), rotation by
-        // selects ((sin, cos) = (0, 1) where nothing rotates) and one 16-byte store. The three-armed form this replaces
-        // compiled to a 4-byte + a 12-byte store per slot and ~145 VALU + 45 SALU per slot of 64-bit index arithmetic
-        // and exec-mask branches (tools/asm_mix.py: 2330 VALU per tile and wave against 540 for the residual epilogue).
-        const int Da = QKV ? p.qkv_heads * p.qkv_head_dim : 1;
-        const int part = QKV ? n / Da : 0;
-        const int nn = QKV ? n - part * Da : 0;
-        const int qh = QKV ? nn / p.qkv_head_dim : 0, qd = QKV ? nn - qh * p.qkv_head_dim : 0;
-        const bool rot_lane = QKV && nok && part < 2;
-        const float q_mult = (QKV && part == 0) ? p.qkv_q_scale : 1.0f;
-        const bool any_rot = QKV && __any(rot_lane);                        // wave-uniform: a v-only strip skips the rotation
-        const int TS = QKV ? p.qkv_heads * p.qkv_tokens_pad * p.qkv_head_dim : 0;        // elements per image tile (< 2^31)
-        bf16_t* const qkv_P0 = QKV ? (bf16_t*)(part == 0 ? p.qkv_q : (part == 1 ? p.qkv_k : p.qkv_v)) +
-                                         ((int64_t)tile_w * p.qkv_heads + qh) * p.qkv_tokens_pad * p.qkv_head_dim + qd
-                                   : nullptr;
-        // Row 0 of the compact table is the identity (sin, cos) = (0, 1) (ABI 14); token tok reads row max(tok - prefix + 1, 0), so the
-        // un-rotated prefix (cls) rows take the identity by INDEX, and a lane that rotates nothing (v columns, columns past N) by a row
-        // pitch of 0 — no per-element selects. One address per slot, both 16-byte halves off it.
-        const float* const sc_P0 = QKV ? p.qkv_sin + (rot_lane ? qd : 0) : nullptr;
-        const unsigned sc_pitch = rot_lane ? (unsigned)p.qkv_head_dim : 0u;
-        auto sc_load = [&](int i, int t, u32x4 (&dst)[2]) {
-            const int m = min(row_of(i, t), p.M - 1);
-            int tile, tok;
-            split_row(m, tile, tok);
-            const unsigned rt = (unsigned)max(tok - p.qkv_prefix + 1, 0);
-#ifdef PP_QKV_NOTABLE     /* diagnostic build: every slot reads the identity row (one L1-resident line) */
-            const float* ptr = sc_P0 + __umul24(rt, 0u);
-#else
-            const float* ptr = sc_P0 + __umul24(rt, sc_pitch);
-#endif
-            dst[0] = *reinterpret_cast<const u32x4*>(ptr);
-            dst[1] = *reinterpret_cast<const u32x4*>(ptr + 4);
-        };
-        // QKV_ROPE_LLM (HF Llama): half-split RoPE — the partner of dim d is d +- hd/2, which the W row order (gar_hip.h) puts
-        // 32 columns away in the SAME 64-column strip: lanes (rr, c) and (rr, c + 4), c < 4, both read x1 = columns 8c.. and
-        // x2 = columns 32 + 8c.. of the wave's fp32-staged row; the first computes x1 cos - x2 sin, the second x2 cos + x1 sin.
-        // Both need the same 8 cos and 8 sin values: the first lane loads the cos, the second the sin (each times the q scale),
-        // and one ds_swizzle (lane ^ 4) per value hands them over — half the loads and half the registers of the prefetch ring.
-        // A strip lies inside one head of one part, so `lpart` is wave-uniform.
-        constexpr bool QKVL = EPI == GAR_EPI_QKV_ROPE_LLM;
-        const int lHD = QKVL ? p.qkv_head_dim : 64, lHALF = lHD >> 1;
-        const int lDq = QKVL ? p.qkv_heads * lHD : 1, lDk = QKVL ? p.qkv_kv_heads * lHD : 1;
-        const int ns = n0 + wn * 64;                                    // first column of the strip (wave-uniform)
-        const int lpart = !QKVL ? 0 : (ns < lDq ? 0 : (ns < lDq + lDk ? 1 : 2));
-        const int lnn = ns - (lpart == 0 ? 0 : (lpart == 1 ? lDq : lDq + lDk));
-        const int lh = lnn / lHD, lj = (lnn - lh * lHD) >> 6;           // head, 64-column strip inside the head
-        const bool l_rot = QKVL && lpart < 2 && ns < p.N;
-        const int l_dh = 32 * lj + (ch & 3) * 8;                        // this lane's column in the [pos, hd/2] tables
-        const int l_d = lpart < 2 ? l_dh + (ch >= 4 ? lHALF : 0) : 64 * lj + ch * 8;
-        const float l_qm = lpart == 0 ? p.qkv_q_scale : 1.0f;
-        const float l_sg = ch >= 4 ? 1.0f : -1.0f;                      // first half: x1 c - x2 s; second half: x2 c + x1 s
-        const float* const l_tab = QKVL ? (ch >= 4 ? p.qkv_sin : p.qkv_cos) + l_dh : nullptr;
-        const int l_hp = lpart == 0 ? p.qkv_heads : p.qkv_kv_heads, l_tp = lpart == 0 ? p.qkv_tokens_pad : p.qkv_kv_stride;
-        const int l_p0 = !QKVL ? 0 : (p.qkv_pos_dev ? p.qkv_pos_dev[0] : p.qkv_pos0);
-        const int l_TS = QKVL ? l_hp * l_tp * lHD : 0;                  // elements per sequence of this part (< 2^31: checked on the host)
-        bf16_t* const l_P0 = !QKVL ? nullptr
-                                   : (bf16_t*)(lpart == 0 ? p.qkv_q : (lpart == 1 ? p.qkv_k : p.qkv_v)) +
-                                         (((int64_t)tile_w * l_hp + lh) * l_tp + (lpart ? l_p0 : 0)) * lHD + l_d;
-        const int l_nb = QKVL ? p.M / TT : 1;
-        const int l_lp0 = (QKVL && p.qkv_left_pad) ? p.qkv_left_pad[min(tile_w, l_nb - 1)] : 0;
-        const int l_lp1 = (QKVL && p.qkv_left_pad) ? p.qkv_left_pad[min(tile_w + 1, l_nb - 1)] : 0;
-        auto l_pos = [&](int i, int t) -> int {                         // RoPE position of slot (i, t)'s token
-            const int m = min(row_of(i, t), p.M - 1);
-            int tile, tok;
-            split_row(m, tile, tok);
-            const int lp = !p.qkv_left_pad ? 0 : (TT >= 128 ? (tile == tile_w ? l_lp0 : l_lp1) : p.qkv_left_pad[tile]);
-            return max(l_p0 + tok - lp, 0);
-        };
-        u32x4 lcs[2][2][2];                                             // [ring][t][values 0..3, 4..7] of this lane's table
-        auto l_load = [&](int i, int slot) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ro = l_pos(i, t) * lHALF;                     // < max_pos * hd / 2: fits 32 bits
-                lcs[slot][t][0] = *reinterpret_cast<const u32x4*>(l_tab + ro);
-                lcs[slot][t][1] = *reinterpret_cast<const u32x4*>(l_tab + ro + 4);
-            }
-        };
-        if (QKVL && l_rot) l_load(0, 0);
-        u32x4 sc[2][2][2];
-        if (QKV) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) sc_load(0, t, sc[0][t]);
-        }
-#ifndef PP_AUX_AHEAD      /* 16-row steps the row-dependent loads run ahead of their use (ring of PP_AUX_AHEAD + 1 slots) */
-#define PP_AUX_AHEAD 2
-#endif
-        constexpr int AH = PP_AUX_AHEAD;
-        u32x4 aux[AH + 1][2];
-        if (HAS_AUX) {
-#pragma unroll
-            for (int i = 0; i < AH; ++i)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) aux[i][t] = aux_load(i, t);
-        }
-        // Staging writes of 16-row step i (this lane's fragments of m-tile i). The steps are software-pipelined: step i + 1 is
-        // written right behind step i's read-back — the LDS runs a wave's requests in order, so the read samples the buffer
-        // before the write lands — and its write -> read turnaround passes under step i's arithmetic and stores instead of in
-        // front of step i + 1's. DIRECT outputs (2 KiB per step) alternate between the two halves of the private 4 KiB, so the
-        // GELU / rounding of step i + 1 also runs while step i's rows come back.
-        auto wave_fence = [&]() {
-            // lanes exchange data through LDS inside one wave: the hardware runs a wave's DS instructions in order, the
-            // fences keep the COMPILER from moving a lane's accesses across the hand-over (no instruction is emitted)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        auto stage_write = [&](int i) {
-            if (DIRECT) {
-                char* const buf = priv + (i & 1) * 2048;
-#pragma unroll
-                for (int jq = 0; jq < 2; ++jq) {
-                    float o[8] = {acc[i][2 * jq][0],     acc[i][2 * jq][1],     acc[i][2 * jq][2],     acc[i][2 * jq][3],
-                                  acc[i][2 * jq + 1][0], acc[i][2 * jq + 1][1], acc[i][2 * jq + 1][2], acc[i][2 * jq + 1][3]};
-                    if (EPI == GAR_EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = gelu_lut(o[e], glut);
-                    }
-                    *reinterpret_cast<u32x4*>(buf + frow_e * 128 + (((jq * 4 + fq_e) ^ ((frow_e >> 1) & 7)) << 4)) =
-                        u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(priv + frow_e * 256 +
-                                              ((((j >> 1) * 8 + fq_e * 2 + (j & 1)) ^ (frow_e & 15)) << 4)) = acc[i][j];
-            }
-        };
-        stage_write(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (HAS_AUX && i + AH < 8) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) aux[(i + AH) % (AH + 1)][t] = aux_load(i + AH, t);
-            }
-            if (QKV && i + 1 < 8) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) sc_load(i + 1, t, sc[(i + 1) & 1][t]);
-            }
-            if (QKVL && l_rot && i + 1 < 8) l_load(i + 1, (i + 1) & 1);
-            if (DIRECT) {
-                const char* const buf = priv + (i & 1) * 2048;
-                wave_fence();
-                u32x4 v2[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = t * 8 + rr;
-                    v2[t] = *reinterpret_cast<const u32x4*>(buf + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-                }
-                wave_fence();
-                if (i + 1 < 8) stage_write(i + 1);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) store_lin(i, t, v2[t]);
-            } else {
-                wave_fence();
-                f32x4 a2[2], b2[2], pa2[2], pb2[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = t * 8 + rr;
-                    a2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2) ^ (row & 15)) << 4));
-                    b2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((ch * 2 + 1) ^ (row & 15)) << 4));
-                    if (QKVL && l_rot) {        // x1 = columns 8 (ch & 3).., x2 = the same 32 columns further, for both lanes of a pair
-                        const int c1 = ch & 3, c2 = c1 + 4;
-                        a2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c1 * 2) ^ (row & 15)) << 4));
-                        b2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c1 * 2 + 1) ^ (row & 15)) << 4));
-                        pa2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c2 * 2) ^ (row & 15)) << 4));
-                        pb2[t] = *reinterpret_cast<const f32x4*>(priv + row * 256 + (((c2 * 2 + 1) ^ (row & 15)) << 4));
-                    }
-                }
-                wave_fence();
-                if (i + 1 < 8) stage_write(i + 1);
-                float stat_s1[2] = {0.f, 0.f}, stat_s2[2] = {0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int m = row_of(i, t);
-                    const f32x4 a = a2[t], b = b2[t];
-                    if (LINEAR || (nok && m < p.M)) {          // LINEAR: every lane computes, the descriptor drops what does not exist
-                        float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                        if (HAS_AUX) {
-                            const u32x4 w = aux[i % (AH + 1)][t];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float lo = unpk_lo(w[e]), hi = unpk_hi(w[e]);
-                                if (EPI == GAR_EPI_BIAS_SCALE_RES) {
-                                    o[2 * e] = lo + gam8[2 * e] * o[2 * e];
-                                    o[2 * e + 1] = hi + gam8[2 * e + 1] * o[2 * e + 1];
-                                } else {
-                                    o[2 * e] += lo;
-                                    o[2 * e + 1] += hi;
-                                }
-                            }
-                        }
-                        if (QKVL) {
-                            int tile, tok;
-                            split_row(m, tile, tok);
-                            if (l_rot) {            // o (= x1 here) and x2; `mine` = cos (first-half lane) / sin (second-half lane)
-                                const f32x4 pa = pa2[t], pb = pb2[t];
-                                const float x2[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const float mine = __uint_as_float(lcs[i & 1][t][e >> 2][e & 3]) * l_qm;
-                                    const float theirs = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mine), 0x101F));   // lane ^ 4
-                                    // first half:  x1 cos - x2 sin = x1 mine - x2 theirs;   second half: x2 cos + x1 sin = x2 theirs + x1 mine
-                                    o[e] = __builtin_fmaf(x2[e], theirs * l_sg, o[e] * mine);
-                                }
-                            }
-                            pp_st8(l_P0 + ((tile - tile_w) * l_TS + tok * lHD), o);
-                        } else if (QKV) {
-                            int tile, tok;
-                            split_row(m, tile, tok);
-                            if (any_rot) {          // rot(x) = (-x[2i+1], x[2i]) on interleaved pairs; q also carries its scale
-                                // three packed instructions per pair: (sn, cs) * q;  t = (x1 sn, x0 sn);  (x0 cs - t.lo, x1 cs + t.hi)
-                                // — the products and their roundings of x0 * cs + (-x1) * sn / x1 * cs + x0 * sn. Pinned: left to
-                                // itself the compiler built both signs of every pair and selected (4 packed + 4 scalar + moves).
-                                typedef float f32v2_e __attribute__((ext_vector_type(2)));
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const u32x4 w = sc[i & 1][t][e >> 1];
-                                    const f32v2_e scq = f32v2_e{__uint_as_float(w[(e & 1) * 2]), __uint_as_float(w[(e & 1) * 2 + 1])} *
-                                                        f32v2_e{q_mult, q_mult};
-                                    const f32v2_e x = {o[2 * e], o[2 * e + 1]};
-                                    f32v2_e tx, r;
-                                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(tx) : "v"(x), "v"(scq));
-                                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1]"
-                                        : "=v"(r) : "v"(x), "v"(scq), "v"(tx));
-                                    o[2 * e] = r[0];
-                                    o[2 * e + 1] = r[1];
-                                }
-                            }
-#ifdef PP_QKV_NOSTORE     /* diagnostic build: the rotated rows are computed and never stored */
-                            if (p.tokens_in == -12345)
-#endif
-                            pp_st8(qkv_P0 + ((tile - tile_w) * TS + tok * p.qkv_head_dim), o);
-                        } else if (STATS_EPI && p.row_stats) {
-                            // folded norm, producer side: (sum, sum of squares) of this row's 64 ROUNDED outputs — 8 per lane,
-                            // the 8 lanes of the row by DPP (quad_perm xor 1, xor 2, row_half_mirror) — one float2 per row and strip
-                            const u32x4 pk = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
-                            // on the packed pairs (v_dot2: exact products, fp32 accumulation): 2 instructions per pair where
-                            // unpack + add + two fma took 5
-                            constexpr unsigned int ONES2 = (unsigned int)H16_ONE * 0x10001u;
-                            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s1 = dot2_acc(pk[e], ONES2, s1);
-                                s2 = dot2_acc(pk[e], pk[e], s2);
-                            }
-                            store_lin(i, t, pk);
-                            stat_s1[t] = s1;
-                            stat_s2[t] = s2;
-                        } else if (LINEAR) {
-                            store_lin(i, t, u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])});
-                        } else {
-                            pp_st8(dst_ptr(i, t, m), o);
-                        }
-                    }
-                }
-                if (STATS_EPI && p.row_stats) {        // all lanes here: columns past N and rows past M contributed 0
-                    // the 8 lanes of a row: lane ^ 1, lane ^ 2 (quad_perm), then the other quad (row_half_mirror) — v_add_f32_dpp
-                    // with the permuted operand in the add itself (update_dpp + add compiled to a v_mov_b32_dpp and an add each).
-                    // Hand-placed: a DPP operand written by the previous VALU instruction needs two wait states, which the four
-                    // interleaved chains provide from the second stage on and the s_nop in front of the first.
-                    asm volatile(
-                        "s_nop 1\n\t"
-                        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf"
-                        : "+v"(stat_s1[0]), "+v"(stat_s2[0]), "+v"(stat_s1[1]), "+v"(stat_s2[1]));
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(stat_s1[t]), __float_as_uint(stat_s2[t])}, rsS,
-                                                              (int)(offS + (unsigned)(i * 16 + t * 8) * st2), 0, 0);
-                    }
-                }
-            }
-            if (i == 0 && wm == 0) __builtin_amdgcn_s_barrier();      // un-stagger: row 1 has finished its last MFMAs by now
-        }
-    };
+#define PP_EPI_PRIV(E) ((E) + wm * PHALF + wn * 4096)
+#define PP_EPI_ATTR
+#define PP_EPI_STEP_HOOK(i) if ((i) == 0 && wm == 0) __builtin_amdgcn_s_barrier();      /* un-stagger: row 1 has finished its last MFMAs by now */
+#include "gemm_epilogue_wave.inc"
 
     int sidx = 0;
     while (true) {
@@ -1259,8 +876,15 @@ bool gar_gemm_pp_takes(const gar_gemm_params& p) {
 }
 
 // returns true if the problem was taken
+#ifdef GAR_GEMM_LW_VARIANT   /* diagnostic build only (tools/gemm_lw/: the round-6 4-wave 128 x 128-per-wave frame — parity with this kernel, not faster) */
+bool gar_gemm_lw_try(const gar_gemm_params& p, hipStream_t s);
+#endif
+
 bool gar_gemm_pp_try(const gar_gemm_params& p, hipStream_t s) {
     if (!gar_gemm_pp_takes(p)) return false;
+#ifdef GAR_GEMM_LW_VARIANT
+    if (gar_gemm_lw_try(p, s)) return true;
+#endif
     const int num_cus = pp_num_cus();
     const int pm = (p.M + PBM - 1) / PBM, pn = (p.N + PBM - 1) / PBM;
     switch (p.epilogue) {

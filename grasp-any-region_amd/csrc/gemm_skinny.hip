@@ -440,12 +440,8 @@ static void launch_skinny(const gar_gemm_params& p, hipStream_t s) {
 // the deep-ring half-tile GEMV (DEEP): M <= 8 rows, narrow output, no norm prologue. false = not applicable.
 template <int EPI>
 static bool launch_skinny_deep(const gar_gemm_params& p, hipStream_t s) {
-    static const int enabled = [] {
-        const char* e = getenv("GAR_SKINNY_DEEP");          // A/B switch (tools/bench_skinny.py)
-        return e ? atoi(e) : 1;
-    }();
     const bool staged = ((int64_t)(p.N - 1) * p.ldw + p.K) * 2 < ((int64_t)1 << 31) && ((int64_t)(p.M - 1) * p.lda + p.K) * 2 < ((int64_t)1 << 31);
-    if (!enabled || !staged || p.M > 8 || p.norm_w || p.norm_folded || p.split_k > 1) return false;
+    if (!staged || p.M > 8 || p.norm_w || p.norm_folded || p.split_k > 1) return false;
     const int nb = (p.N + 7) / 8, ksteps = p.K / 64;
     constexpr int MAXLDS = 139264;
     static gar_once_per_device attr_once;

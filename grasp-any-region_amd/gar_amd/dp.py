@@ -9,7 +9,7 @@ No activation ever crosses xGMI; there is no all-reduce on the path."""
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -35,38 +35,6 @@ def init_distributed(backend: Optional[str] = None):
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Round-robin partition: rank r takes items i with i % world == r."""
     return list(range(rank, n_items, world))
-
-
-def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20):
-    """Broadcast a list of same-dtype device tensors in flat buckets (few large xGMI transfers instead of ~400 small)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    tensors = list(tensors)
-    by_dtype = {}
-    for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
-    for dt, ts in by_dtype.items():
-        bucket, size = [], 0
-        for t in ts + [None]:
-            if t is not None and size + t.numel() * t.element_size() <= bucket_bytes:
-                bucket.append(t)
-                size += t.numel() * t.element_size()
-                continue
-            if bucket:
-                flat = torch.cat([b.reshape(-1) for b in bucket])
-                dist.broadcast(flat, src=src)
-                off = 0
-                for b in bucket:
-                    b.copy_(flat[off:off + b.numel()].view_as(b))
-                    off += b.numel()
-            bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
-        if bucket:
-            flat = torch.cat([b.reshape(-1) for b in bucket])
-            dist.broadcast(flat, src=src)
-            off = 0
-            for b in bucket:
-                b.copy_(flat[off:off + b.numel()].view_as(b))
-                off += b.numel()
 
 
 def broadcast_arenas(arenas, src: int = 0) -> int:

@@ -63,7 +63,6 @@ SIGNATURES = {
     "gar_llm_qkv_post": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp], _i),
     "gar_attention": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "gar_attention_vrow": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
-    "gar_attention_v4_enable": ([_i], _i),
     "gar_attention_decode_workspace": ([_i, _i, _i, _i], _i64),
     "gar_attention_decode": ([_i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gar_attention_decode_qkv": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp], _i),

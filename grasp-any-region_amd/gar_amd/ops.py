@@ -396,16 +396,6 @@ def attention(Q, K, Vt, O, B, Hq, Hkv, hd, q_len, q_pad, kv_len, kv_stride, caus
         flops=4.0 * B * Hq * hd * pairs)
 
 
-def attention_v4_enable(on: int) -> int:
-    """opt-in switch of the 4-wave persistent attention kernel (both libraries); returns the previous state of the bf16 one"""
-    prev = int(lib(torch.bfloat16).gar_attention_v4_enable(int(on)))
-    try:
-        lib(torch.float16).gar_attention_v4_enable(int(on))
-    except hip.GarError:
-        pass
-    return prev
-
-
 def attention_decode(q, Kc, Vc, O, B, Hq, Hkv, hd, Smax, kv_len_dev, max_splits, workspace, kv_start=None,
                      q_stride: int = 0):
     """``q_stride`` (elements between the query rows of consecutive (b, head); 0 = hd, the packed [B, Hq, hd] form): with

@@ -246,12 +246,6 @@ int gar_attention_vrow(int dtype, const void* Q, const void* K, const void* V, v
                        int q_len, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                        const int32_t* kv_start, int kv_prefix, gar_stream_t stream);
 
-/* Opt-in switch of the 4-wave persistent attention kernel `attn_bf16_v4` (csrc/attention_v4.hip; bf16 / fp16, head_dim 64, row-major V,
- * >= 256 query rows: the ViT tile attention of modeling_perception_lm.py:210-214 and the causal GQA prefill of modeling_gar.py:40-43
- * behind gar_attention_vrow). on = 1 / 0 sets it, on < 0 only queries; returns the previous state. Initial state: the environment
- * variable GAR_ATTN_V4 (default off: parity-green, but slower than the v2 kernel at head_dim 64 — DESIGN.md section 9). */
-int gar_attention_v4_enable(int on);
-
 /* Single-token decode attention over the KV cache (the per-token LlamaModel step of HF's greedy loop,
  * modeling_gar.py:418-426): split-KV, the Hq/Hkv query heads of a kv head share one pass over K / V.
  * q: the query row of (b, head) starts at q + (b*Hq + head) * q_stride elements (q_stride = hd, or 0, for the packed

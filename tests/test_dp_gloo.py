@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the data-parallel runner's collectives (bucketed weight broadcast, caption gather,
+"""CPU, world_size 2 over gloo: the data-parallel runner's collectives (one weight broadcast per dtype arena, caption gather,
 barrier, max-over-ranks) and the region sharding — the N > 1 path of bench.py without a GPU."""
 import os
 import socket
@@ -26,13 +26,9 @@ def _worker(rank, world, port, out_dir):
     from gar_amd import dp
     r, l, w = dp.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
-    # ---- bucketed broadcast of "weights" (several dtypes, sizes around the bucket boundary)
     g = torch.Generator().manual_seed(123)
     ref = [torch.randn(1000, generator=g), torch.randn(7, 13, generator=g), torch.randn(50000, generator=g),
            torch.randint(0, 100, (33,), generator=g), torch.randn(3, generator=g).to(torch.bfloat16)]
-    mine = [t.clone() if rank == 0 else torch.zeros_like(t) for t in ref]
-    dp.broadcast_tensors(mine, src=0, bucket_bytes=64 * 1024)
-    assert all(torch.equal(a, b) for a, b in zip(mine, ref))
     # ---- the replica's weights as ONE arena per dtype: one in-place collective per arena, bit-equal replicas
     import torch.distributed as dist
     from gar_amd.weights import ARENA_ALIGN_BYTES, pack_arenas
@@ -97,6 +93,6 @@ def test_single_process_paths_are_noops():
     from gar_amd import dp
     t = torch.arange(6).view(2, 3)
     assert dp.gather_captions(t)[0] is t
-    dp.broadcast_tensors([t])
+    assert dp.broadcast_arenas({t.dtype: t}) == 0
     dp.barrier()
     assert dp.max_over_ranks(3.5) == 3.5

@@ -880,26 +880,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-// Opt-in (round 5): the kernel is parity-green but slower than v2 at head_dim 64 (profiles/r5_attention_v4.txt).
-// Initial state from the environment (GAR_ATTN_V4=1), changed at run time through gar_attention_v4_enable().
-static int v4_switch(int set) {
-    static int state = [] {
-        const char* e = getenv("GAR_ATTN_V4");
-        return e ? (atoi(e) != 0) : 0;
-    }();
-    const int prev = state;
-    if (set >= 0) state = set != 0;
-    return prev;
-}
-extern "C" int gar_attention_v4_enable(int on) { return v4_switch(on); }
-
+// Diagnostic build only since round 6 (tools/attn_v4/README.md): the variant library takes every shape the kernel is built for.
 // returns false when this kernel does not apply (the caller keeps attn_bf16_v2): head_dim 64, row-major V, whole kv tiles in
 // the slab (kv_stride % 64 == 0), at least 256 query rows per item.
 bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, int B, int Hq, int Hkv, int hd, int q_row0,
                           int q_len, int q_total, int q_pad, int kv_len, int kv_stride, int causal, const int32_t* kv_len_dev,
                           const int32_t* kv_start, int kv_prefix, hipStream_t s) {
-    const int enabled = v4_switch(-1);
-    if (!enabled || hd != 64 || q_len < 256 || (int64_t)kv_stride * 128 >= ((int64_t)1 << 31) || (int64_t)q_pad * 128 >= ((int64_t)1 << 31))
+    if (hd != 64 || q_len < 256 || (int64_t)kv_stride * 128 >= ((int64_t)1 << 31) || (int64_t)q_pad * 128 >= ((int64_t)1 << 31))
         return false;
     if ((kv_stride & 63) != 0 || Hq % Hkv != 0) return false;
     v4_args a;
@@ -917,7 +904,9 @@ bool gar_attn_bf16_v4_try(const void* Q, const void* K, const void* V, void* O, 
     });
     const int cus = gar_num_cus();
     int grid = (int)(n_items < cus ? n_items : cus);
-    if (const char* e = getenv("GAR_ATTN_V4_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;      // diagnostics
+#ifdef V4_GRID
+    grid = V4_GRID < grid ? V4_GRID : grid;      // timeline builds
+#endif
     if (causal) hipLaunchKernelGGL(attn_bf16_v4_kernel<true>, dim3(grid), dim3(256), V4_LDS, s, a);
     else hipLaunchKernelGGL(attn_bf16_v4_kernel<false>, dim3(grid), dim3(256), V4_LDS, s, a);
     return true;
