@@ -74,6 +74,9 @@ def parse(argv=None):
                          "image tiles into LDS)")
     ap.add_argument("--vit-v-transpose", action="store_true",
                     help="A/B: ViT v through gar_vit_v_transpose + Vt attention instead of the row-major form")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the launch plan of --gpus N as one JSON object (command, per-rank device / regions / host threads / GPU "
+                         "NUMA node, collectives) and exit: nothing is started, no GPU is touched")
     ap.add_argument("--runtime", default=None,
                     help="module:attr of a runtime object replacing GpuRuntime (tests/bench_stub.py: a CPU stub under gloo, so that "
                          "the N > 1 control flow and the self-launch run on a box without GPUs); never set for a measurement")
@@ -121,13 +124,47 @@ def build_sample(workload, proc, i, device="cpu"):
                                       device=device)[0]
 
 
+def region_index(rank: int, world: int, j: int) -> int:
+    """the global index of the j-th region a rank serves: regions are dealt round-robin, i % world == rank"""
+    return rank + world * j
+
+
+def launch_plan(args) -> dict:
+    """`--dry-run`: what `--gpus N` WOULD start on this box — the launch command, and per rank its device, the regions it serves,
+    its share of the host cores and the NUMA node of its GPU where the sysfs says — without touching a GPU (VERDICT r5 next #7)."""
+    n = args.gpus
+    cores = os.cpu_count() or n
+    ranks = []
+    for r in range(n):
+        numa = None
+        try:        # /sys/class/drm/cardN/device/numa_node of the r-th render device, when present
+            cards = sorted(d for d in os.listdir("/sys/class/drm") if d.startswith("card") and d[4:].isdigit())
+            if r < len(cards):
+                numa = int(open(f"/sys/class/drm/{cards[r]}/device/numa_node").read().strip())
+        except (OSError, ValueError):
+            pass
+        ranks.append({"rank": r, "local_rank": r, "device": f"cuda:{r}", "torch_threads": max(1, cores // n),
+                      "gpu_numa_node": numa,
+                      "regions": f"i % {n} == {r}: " + ", ".join(str(region_index(r, n, j)) for j in range(3)) + ", ...",
+                      "regions_per_step": args.batch})
+    return {"dry_run": True, "n_gpus": n, "backend": "nccl (RCCL over xGMI)",
+            "launch": f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node={n} --master-addr 127.0.0.1 "
+                      f"--master-port <free port> {os.path.abspath(__file__)} --gpus {n} --steps {args.steps} --warmup {args.warmup}",
+            "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+            "collectives": {"weight_broadcast": "one in-place broadcast per dtype arena from rank 0 (2 for GAR-1B: bf16 + f32 tables)",
+                            "per_step": f"gather of [{args.batch}, {args.new_tokens}] int64 caption ids to rank 0 -> [{n * args.batch}, {args.new_tokens}]",
+                            "timed_region": "barrier + synchronize on both sides, max over ranks"},
+            "ranks": ranks}
+
+
 def build_batches(cfg, proc, rank, world, B, pool, device, workload="single", distinct=0):
     """`pool` batches of B samples each, resident on the GPU in bf16 before the timed region. Every region of every
     batch is its own synthetic image + mask (seeded by rank, batch and slot), built with the DEVICE preprocessor
     (csrc/preprocess.hip: bit-exact with the host processor, ~10 ms of host work per region instead of ~450 ms of CPU
     bicubic). ``distinct`` > 0 caps the number of different samples (they are then repeated; A/B only)."""
     n = pool * B if distinct <= 0 else min(pool * B, distinct)
-    singles = [build_sample(workload, proc, rank * 100000 + j, device) for j in range(n)]
+    # region i of the job runs on rank i % world (SURVEY.md 8e): rank r builds regions r, r + world, r + 2 world, ...
+    singles = [build_sample(workload, proc, region_index(rank, world, j), device) for j in range(n)]
     batches = []
     for pidx in range(pool):
         sel = [singles[(pidx * B + k) % len(singles)] for k in range(B)]
@@ -433,6 +470,9 @@ def main(argv=None, runtime=None):
     global HALF_DT
     args = parse(argv)
     HALF_DT = torch.float16 if args.data_type == "fp16" else torch.bfloat16
+    if args.dry_run:
+        print(json.dumps(launch_plan(args)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and runtime is None:
         rc = self_launch(args, argv)
         if rc:
@@ -469,7 +509,7 @@ def main(argv=None, runtime=None):
         from gar_amd.eval_dataset import SingleRegionCaptionDataset
         from gar_amd.synthetic import synthetic_image, synthetic_mask
         gproc = GARProcessor.from_config(cfg, max_num_tiles=args.max_num_tiles).use_gpu_preprocessing(device, HALF_DT)
-        raw = [(synthetic_image(rank * 1000 + j), synthetic_mask(rank * 1000 + j)) for j in range(4)]
+        raw = [(synthetic_image(region_index(rank, world, j)), synthetic_mask(region_index(rank, world, j))) for j in range(4)]
 
         def make_batch(i):
             sel = [SingleRegionCaptionDataset(*raw[(i * B + k) % len(raw)], gproc, data_dtype=HALF_DT,
@@ -568,8 +608,10 @@ def main(argv=None, runtime=None):
     my_elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(my_elapsed, device)
     per_rank = dp.all_gather_floats(my_elapsed, device)             # every rank's own clock around the same K steps
+    gathered_shape = None
     if rank == 0:       # every rank's [B, new_tokens] ids arrived on rank 0 in the last step
         assert caps is not None and len(caps) == world and all(tuple(c.shape) == (args.batch, args.new_tokens) for c in caps)
+        gathered_shape = list(torch.cat([c.cpu() for c in caps]).shape)        # [world * B, new_tokens] on rank 0
     timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
     bad_inputs = 0
     for f in input_flags:
@@ -691,6 +733,8 @@ def main(argv=None, runtime=None):
             "roofline": roof,
             "parity_pins": parity_pins(),
             **dp.describe(),
+            "caption_gather": {"rank0_ids_shape": gathered_shape, "per_step": True,
+                               "region_partition": f"region i runs on rank i % {world} (rank r: r, r + {world}, r + {2 * world}, ...)"},
             "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
             "weight_broadcast": {"seconds": bcast_s, "bytes": bcast_bytes, "collectives": bcast_n,
                                  "note": "ONE in-place broadcast per dtype arena of the prepared weights (bytes = the arena) from rank 0 "

@@ -309,7 +309,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* __restrict
                                                              const int32_t* __restrict__ step_dev, int64_t* __restrict__ cur_tokens,
                                                              const float* __restrict__ params, const int64_t* __restrict__ seed_dev,
                                                              const int64_t* __restrict__ eos_ids, int n_eos,
-                                                             int32_t* __restrict__ finished, int32_t* __restrict__ done_count) {
+                                                             int32_t* __restrict__ finished, int32_t* __restrict__ done_count,
+                                                             int row_offset) {
     __shared__ float hist_f[SMP_WAVES][256];        // per-wave mass histograms (merged in wave order: deterministic)
     __shared__ int hist_i[256];
     __shared__ float red_f[SMP_WAVES];
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* __restrict
         float Z2 = 0.f;
         for (int w = 0; w < SMP_WAVES; ++w) Z2 += red_f[w];
         const unsigned long long seed = (unsigned long long)seed_dev[0];
-        const unsigned int r = philox_first((unsigned int)step, (unsigned int)b, 0u, 0u, (unsigned int)seed, (unsigned int)(seed >> 32));
+        const unsigned int r = philox_first((unsigned int)step, (unsigned int)(b + row_offset), 0u, 0u, (unsigned int)seed, (unsigned int)(seed >> 32));
         const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
         const float target = u * Z2;
         // segment, then chunk, then (below) element: running sums in the same fixed order
@@ -520,16 +521,17 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const T* __restrict
 
 extern "C" int gar_sample(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
                           const int32_t* step_dev, int64_t* cur_tokens, const float* params_dev, const int64_t* seed_dev,
-                          const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream) {
-    GAR_CHECK_ARG(logits && params_dev && seed_dev && B > 0 && V > 0 && (out_tokens || cur_tokens), "sample: bad args");
+                          const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, int row_offset,
+                          gar_stream_t stream) {
+    GAR_CHECK_ARG(logits && params_dev && seed_dev && B > 0 && V > 0 && (out_tokens || cur_tokens) && row_offset >= 0, "sample: bad args");
     GAR_CHECK_ARG(n_eos >= 0 && (n_eos == 0 || eos_ids) && (!finished || eos_ids), "sample: eos_ids / finished");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GAR_BF16)
         hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(B), dim3(SMP_THREADS), 0, s, (const bf16_t*)logits, ld, V, out_tokens, out_stride,
-                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count);
+                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count, row_offset);
     else
         hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(SMP_THREADS), 0, s, (const float*)logits, ld, V, out_tokens, out_stride,
-                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count);
+                           step_dev, cur_tokens, params_dev, seed_dev, eos_ids, n_eos, finished, done_count, row_offset);
     GAR_CHECK_LAUNCH();
     return GAR_OK;
 }

@@ -50,12 +50,19 @@ class ContinuousBatcher:
     ``pump()`` advances the loop while there is more queued than ``lookahead``; ``flush()`` runs everything to completion.
     Finished captions appear in ``results`` (ticket -> token ids, its own eos included) and ``pop_finished()``."""
 
-    DEC_SLOT, STAGE_SLOT = 2, 3          # KV-state slots of the model (0 / 1 belong to generate / GenerationPipeline)
+    FIRST_SLOT = 2                       # KV-state slots 0 / 1 of the model belong to generate / GenerationPipeline
+    STARVE_CYCLES = 8                    # admission cycles a queue head may be passed over before the loop drains for it
 
     def __init__(self, model, slots: int, max_new_tokens: int = 1024, eos_token_id=None, poll_every: int = 8,
                  admit_min: Optional[int] = None, lookahead: Optional[int] = None, horizon: Optional[int] = None,
                  validate: bool = True, use_graph: bool = True, smax_multiple: int = 256):
         self.model, self.B = model, int(slots)
+        # every batcher owns its two KV-state slots (decode / staging) of the model: two batchers — or a batcher and a caller of
+        # generate(state_slot=...) — on one model never share a cache, token log, eos latches or graph (ADVICE r5)
+        base = getattr(model, "_next_batcher_slot", self.FIRST_SLOT)
+        self.DEC_SLOT, self.STAGE_SLOT = base, base + 1
+        model._next_batcher_slot = base + 2
+        self._head_waits = 0             # cycles the queue's head has been pushed back (prompt longer than the shared clock)
         self.max_new = int(max_new_tokens)
         eos = [] if eos_token_id is None else ([int(e) for e in eos_token_id] if isinstance(eos_token_id, (list, tuple))
                                                else [int(eos_token_id)])
@@ -178,10 +185,15 @@ class ContinuousBatcher:
         if not free or not self.queue:
             return
         idle = len(free) == self.B
-        if not (flushing or idle) and (len(free) < self.admit_min or len(self.queue) < min(self.admit_min, len(free))):
+        # a head that does not fit the running clock has waited long enough: admit nothing until the loop is idle — the clock then
+        # restarts at ITS length (later, shorter prompts must not keep the rows busy for ever)
+        if self._head_waits >= self.STARVE_CYCLES and not idle:
             return
         # a group = the queue's head and what follows it with the same tile count / modality, as many as there are free rows
         key = self._group_key(self.queue[0][1])
+        n_match = sum(1 for _, smp in self.queue if self._group_key(smp) == key)
+        if not (flushing or idle) and (len(free) < self.admit_min or n_match < min(self.admit_min, len(free))):
+            return                       # (gated on the size of the MATCHING group: a prompt phase for one region starves the tile GEMMs)
         group, rest = [], deque()
         while self.queue:
             item = self.queue.popleft()
@@ -190,6 +202,7 @@ class ContinuousBatcher:
             else:
                 rest.append(item)
         self.queue = rest
+        head_ticket = group[0][0]
         lens = [int(s["input_ids"].shape[1]) for _, s in group]
         if idle:
             self._new_base(max(lens))
@@ -206,8 +219,11 @@ class ContinuousBatcher:
             for item in reversed(back):
                 self.queue.appendleft(item)
             group = keep
+            self._head_waits = self._head_waits + 1 if (back and back[0][0] == head_ticket) else 0
             if not group:
                 return
+        if idle:
+            self._head_waits = 0
         self._prompt_phase_and_admit(group, free)
 
     def _new_base(self, n_max: int):

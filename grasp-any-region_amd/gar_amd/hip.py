@@ -18,7 +18,7 @@ GAR_F32, GAR_BF16 = 0, 1
 (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_RES, EPI_SWIGLU, EPI_PATCH_POS, EPI_QKV_ROPE,
  EPI_QKV_ROPE_LLM) = range(9)
 ERR_UNSUPPORTED = -4
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class GarError(RuntimeError):
@@ -80,7 +80,7 @@ SIGNATURES = {
     "gar_embed_lookup": ([_i, _vp, _vp, _vp, _i, _i, _i64, _vp], _i),
     "gar_argmax": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "gar_argmax_workspace": ([_i, _i], _i64),
-    "gar_sample": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
+    "gar_sample": ([_i, _vp, _i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp], _i),
     "gar_counter_add": ([_vp, _i, _i, _vp], _i),
     "gar_input_check": ([_vp, _i, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
 }

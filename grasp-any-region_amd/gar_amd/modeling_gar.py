@@ -78,6 +78,23 @@ _NEUTRAL_GENERATION_OPTIONS = {
 _SAMPLING_ONLY_OPTIONS = ("temperature", "top_k", "top_p", "min_p", "typical_p", "epsilon_cutoff", "eta_cutoff")
 
 
+# keywords generate() accepts besides its own parameters: the generation options it reads or refuses by value
+_GENERATION_KWARGS = set(_NEUTRAL_GENERATION_OPTIONS) | {"do_sample", "temperature", "top_k", "top_p", "min_p", "typical_p", "epsilon_cutoff",
+                                                          "eta_cutoff", "max_new_tokens", "eos_token_id", "pad_token_id", "use_cache",
+                                                          "return_dict_in_generate", "output_scores", "output_logits", "output_attentions",
+                                                          "synced_gpus", "streamer", "labels"}
+
+
+class _OverlaidOptions:
+    """generation options: keyword arguments laid over a GenerationConfig / dict (HF: `generate(generation_config, **kwargs)`)"""
+
+    def __init__(self, base_get, over):
+        self._base, self._over = base_get, over
+
+    def get(self, k, d=None):
+        return self._over[k] if k in self._over else self._base(k, d)
+
+
 def _refuse_non_greedy(get):
     for name, neutral in _NEUTRAL_GENERATION_OPTIONS.items():
         v = get(name)
@@ -1052,7 +1069,7 @@ class GARModel:
         return self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
 
     def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None,
-              finished=None):
+              finished=None, row0: int = 0):
         """final RMSNorm + lm_head + greedy argmax of the given [B, C] rows (row-strided view allowed). ``normed``: the
         rows after the final norm, when the caller's last launch produced them already (split-K decode path)."""
         cur = st["cur"] if cur is None else cur
@@ -1073,7 +1090,7 @@ class GARModel:
         fin = st["finished"] if finished is None else finished
         if st.get("sampling"):
             ops.sample(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, st["sample_params"], st["sample_seed"],
-                       eos_ids=st["eos_ids"], finished=fin, done_count=st["done_count"])
+                       eos_ids=st["eos_ids"], finished=fin, done_count=st["done_count"], row_offset=row0)
         else:
             ops.argmax(logits, V, out_tokens, out_tokens.stride(0), st["counters"][2:3], cur, ws, eos_ids=st["eos_ids"],
                        finished=fin, done_count=st["done_count"])
@@ -1228,8 +1245,19 @@ class GARModel:
         compared on identical contexts over a whole caption."""
         gc = generation_config
         sampling = None
+        if generate_kwargs:
+            # the reference forwards **generate_kwargs to HF's generate (modeling_gar.py:418-426), which lays them OVER the generation
+            # config: the same here — an option passed as a keyword is read (and refused if not built) like one in the config, never
+            # swallowed; a keyword that is no generation option at all is an error as it is in HF (ADVICE r5)
+            unknown = sorted(k for k in generate_kwargs if k not in _GENERATION_KWARGS)
+            if unknown:
+                raise TypeError(f"generate() got unexpected keyword arguments {unknown} (generation options: see GenerationConfig)")
+            base = gc
+            base_get = (lambda k, d=None: d) if base is None else \
+                ((lambda k, d=None: base.get(k, d)) if isinstance(base, dict) else (lambda k, d=None: getattr(base, k, d)))
+            gc = _OverlaidOptions(base_get, dict(generate_kwargs))
         if gc is not None:
-            get = (lambda k, d=None: gc.get(k, d)) if isinstance(gc, dict) else (lambda k, d=None: getattr(gc, k, d))
+            get = gc.get if isinstance(gc, (dict, _OverlaidOptions)) else (lambda k, d=None: getattr(gc, k, d))
             _refuse_non_greedy(get)
             if get("do_sample", False):
                 sampling = _sampling_options(get)
@@ -1288,6 +1316,9 @@ class GARModel:
         if sampling is not None:
             if seed is None:          # HF draws from torch's global generator: so does the key of this request (torch.manual_seed reproduces it)
                 seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    # identically seeded data-parallel ranks must not replay one stream on different regions
+                    seed = (seed ^ (0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1))) & (2 ** 62 - 1)
             st["sample_params"].copy_(torch.tensor([sampling[0], sampling[1], float(sampling[2]), 0.0]).pin_memory(), non_blocking=True)
             st["sample_seed"].copy_(torch.tensor([int(seed)], dtype=torch.int64).pin_memory(), non_blocking=True)
         V = cfg.mllm_config.text_config.vocab_size
@@ -1337,7 +1368,7 @@ class GARModel:
                 embeds = self._buf(("emb", b1 - b0, S), "embeds", (b1 - b0, S, cfg.mllm_config.text_config.hidden_size))
                 ops.embed_assemble(ids_c.to(self.device, torch.int64).contiguous(), None, self.E, None, embeds, 0)
             last = self._prefill(embeds, st, Smax, b0)
-            lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1], finished=st["finished"][b0:b1])
+            lg = self._head(last, b1 - b0, out_tokens[b0:b1], st, cur=st["cur"][b0:b1], finished=st["finished"][b0:b1], row0=b0)
             if forced_tokens is not None:
                 st["cur"][b0:b1].copy_(forced_tokens[b0:b1, 0])
             if return_logits:

@@ -544,9 +544,12 @@ def argmax(logits, V, out_tokens, out_stride, step_dev, cur_tokens, workspace, e
                            0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), stream()), "gar_argmax")
 
 
-def sample(logits, V, out_tokens, out_stride, step_dev, cur_tokens, params, seed, eos_ids=None, finished=None, done_count=None):
+def sample(logits, V, out_tokens, out_stride, step_dev, cur_tokens, params, seed, eos_ids=None, finished=None, done_count=None,
+           row_offset: int = 0):
     """do_sample = True: temperature / top-k / top-p + one Philox draw per row (``gar_sample``). ``params`` float32 [3] (device):
-    temperature, top_p, top_k; ``seed`` int64 [1] (device). Token placement and eos latches as :func:`argmax`."""
+    temperature, top_p, top_k; ``seed`` int64 [1] (device). Token placement and eos latches as :func:`argmax`. ``row_offset``: the
+    batch row of ``logits[0]`` — the draw of row b is counted by (step, row_offset + b), so a batch whose first tokens come out of several
+    prompt chunks draws what the un-chunked batch draws (ABI 15)."""
     B = logits.shape[0]
     assert params.dtype == torch.float32 and params.numel() >= 3 and params.is_contiguous()
     assert seed.dtype == torch.int64 and seed.numel() >= 1
@@ -555,7 +558,8 @@ def sample(logits, V, out_tokens, out_stride, step_dev, cur_tokens, params, seed
                                 and finished.numel() == B)
     check(lib(logits.dtype).gar_sample(dtype_code(logits.dtype), ptr(logits), logits.stride(0), B, V, ptr(out_tokens), out_stride,
                                        ptr(step_dev), ptr(cur_tokens), ptr(params), ptr(seed), ptr(eos_ids),
-                                       0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), stream()),
+                                       0 if eos_ids is None else eos_ids.numel(), ptr(finished), ptr(done_count), int(row_offset),
+                                       stream()),
           "gar_sample")
 
 

@@ -38,7 +38,7 @@ extern "C" {
 #define GAR_F32 0
 #define GAR_BF16 1
 
-#define GAR_ABI_VERSION 14
+#define GAR_ABI_VERSION 15
 
 /* GEMM epilogues */
 #define GAR_EPI_NONE 0            /* C = A W^T                                               */
@@ -369,16 +369,6 @@ int gar_argmax(int dtype, const void* logits, int64_t ld, int B, int V, int64_t*
                 * number of latched rows). All three may be NULL (n_eos = 0): plain argmax. */
                const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream);
 int64_t gar_argmax_workspace(int B, int V);
-/* do_sample = True (ABI 13): HF's TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> one multinomial draw
- * (transformers GenerationMixin._sample; the reference forwards the caller's GenerationConfig, modeling_gar.py:418-426), on the
- * device and hipGraph-replayable: params_dev float [3] = {temperature > 0, top_p in (0, 1] (1 = off), top_k (0 or >= V = off)},
- * seed_dev int64 [1]; the draw of (row b, step step_dev[0]) is Philox4x32-10(key = seed, counter = (step, b, 0, 0)), 24 bits ->
- * u in [0, 1), and the token is the first index in vocabulary order whose running sum of kept exp((logit - max) / T) exceeds
- * u x their total (oracle/sampling.py restates kernel and RNG; tests/test_oracle_goldens.py pins its kept set against
- * transformers' warpers). Token placement and the eos latches are gar_argmax's. */
-int gar_sample(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
-               const int32_t* step_dev, int64_t* cur_tokens, const float* params_dev, const int64_t* seed_dev,
-               const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, gar_stream_t stream);
 int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 
 /* The input checks of the reference's generate() without a host sync: image-token count vs feature rows (ValueError,
@@ -392,6 +382,23 @@ int gar_counter_add(int32_t* counters, int n, int delta, gar_stream_t stream);
 int gar_input_check(const int64_t* input_ids, int B, int S, int64_t vocab, const int32_t* counts, int n_rows,
                     const int32_t* spans, int n_crop, int span_len, const int32_t* has_box, int32_t* flags,
                     const uint8_t* attn_mask, gar_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * EXTRAS — not on the path BASELINE.json's north_star names (greedy decode; every reference caller passes do_sample=False,
+ * demo/gar_with_mask.py:115-121). Kept because the reference forwards ANY GenerationConfig to HF's generate
+ * (modeling_gar.py:418-426); nothing in the timed benchmark path calls into this section.
+ * ------------------------------------------------------------------------------------------------------------------------- */
+/* do_sample = True (ABI 13): HF's TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> one multinomial draw
+ * (transformers GenerationMixin._sample; the reference forwards the caller's GenerationConfig, modeling_gar.py:418-426), on the
+ * device and hipGraph-replayable: params_dev float [3] = {temperature > 0, top_p in (0, 1] (1 = off), top_k (0 or >= V = off)},
+ * seed_dev int64 [1]; the draw of (row b, step step_dev[0]) is Philox4x32-10(key = seed, counter = (step, row_offset + b, 0, 0)) — row_offset
+ * (ABI 15) = the batch row of logits[0], for callers that produce a batch's tokens in several launches (prompt chunks) —, 24 bits ->
+ * u in [0, 1), and the token is the first index in vocabulary order whose running sum of kept exp((logit - max) / T) exceeds
+ * u x their total (oracle/sampling.py restates kernel and RNG; tests/test_oracle_goldens.py pins its kept set against
+ * transformers' warpers). Token placement and the eos latches are gar_argmax's. */
+int gar_sample(int dtype, const void* logits, int64_t ld, int B, int V, int64_t* out_tokens, int64_t out_stride,
+               const int32_t* step_dev, int64_t* cur_tokens, const float* params_dev, const int64_t* seed_dev,
+               const int64_t* eos_ids, int n_eos, int32_t* finished, int32_t* done_count, int row_offset, gar_stream_t stream);
 
 #ifdef __cplusplus
 }

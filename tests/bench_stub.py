@@ -61,7 +61,8 @@ class StubRuntime:
         batches = []
         for pidx in range(args.pool):
             ids = torch.full((B, S), 7, dtype=torch.int64)
-            ids[:, 0] = 1000 * rank + 10 * pidx + torch.arange(B)
+            import bench
+            ids[:, 0] = torch.tensor([bench.region_index(rank, world, pidx * B + k) for k in range(B)])     # the region index itself
             batches.append(dict(input_ids=ids, pixel_values=torch.zeros(B * tiles, 3, 4, 4),
                                 global_mask_values=torch.zeros(B * tiles, 3, 4, 4), bboxes=[{}] * B,
                                 aspect_ratios=torch.ones(B, 2, dtype=torch.int64)))

@@ -29,8 +29,12 @@ def _worker(rank, world, port, out_dir):
                       MASTER_PORT=str(port))
     import bench
     import bench_stub
+    from gar_amd import dp
     log = bench_stub.LOG
     StubRuntime = bench_stub.StubRuntime
+    gathered = []
+    real_gather = dp.gather_captions
+    dp.gather_captions = lambda ids, dst=0: (gathered.append(real_gather(ids, dst=dst)), gathered[-1])[1]
 
     buf = io.StringIO()
     old, sys.stdout = sys.stdout, buf
@@ -40,8 +44,11 @@ def _worker(rank, world, port, out_dir):
     finally:
         sys.stdout = old
     assert log["generate_calls"] == 5 and log["syncs"] == 6          # 2 around the weight broadcast + 4 around the timed region
+    last = gathered[-1]
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
-        json.dump({"stdout": buf.getvalue(), "threads": torch.get_num_threads()}, f)
+        json.dump({"stdout": buf.getvalue(), "threads": torch.get_num_threads(), "gathers": len(gathered),
+                   # the stub's first token of a caption is 3 x the region index it was asked for
+                   "last_gather_regions": None if last is None else [[int(t) // 3 for t in part[:, 0]] for part in last]}, f)
     torch.distributed.destroy_process_group()
 
 
@@ -91,3 +98,41 @@ def test_plain_python_invocation_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--runtime",
                           "bench_stub:StubRuntime", "--no-cpu-baseline"], env=env2, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_control_flow_world8(tmp_path):
+    """the shape of the driver's SCALE run at N = 8 (CPU stub, gloo): eight ranks seen, ONE broadcast per weight arena, every step's
+    [8 x B, new_tokens] ids on rank 0, and region i served by rank i % 8. No hardware is involved: the
+    1 -> 8 GPU curve itself stays unmeasured from this container."""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert all(o["stdout"].strip() == "" for o in outs[1:])
+    lines = [ln for ln in outs[0]["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["backend"] == "gloo" and len(d["per_rank_ms_per_step"]) == 8
+    assert d["weight_broadcast"]["collectives"] == 2 and d["weight_broadcast"]["bytes"] == 3000 * 4 + 17 * 8
+    assert d["caption_gather"]["rank0_ids_shape"] == [8 * 4, 5] and d["config"]["parallelism"].startswith("dp8")
+    assert abs(d["value"] - 8 * 3 * 4 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
+    assert all(o["gathers"] == 5 for o in outs)                    # one gather per step (2 warm-up + 3 timed), on every rank
+    assert all(o["last_gather_regions"] is None for o in outs[1:])
+    parts = outs[0]["last_gather_regions"]
+    assert len(parts) == 8
+    seen = set()
+    for r, regions in enumerate(parts):
+        assert len(regions) == 4 and all(i % 8 == r for i in regions), (r, regions)
+        seen |= set(regions)
+    assert len(seen) == 32
+
+
+def test_dry_run_prints_the_launch_plan():
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["dry_run"] and d["n_gpus"] == 8 and len(d["ranks"]) == 8 and "--nproc-per-node=8" in d["launch"]
+    assert [r["device"] for r in d["ranks"]] == [f"cuda:{i}" for i in range(8)]
+    assert d["ranks"][5]["regions"].startswith("i % 8 == 5: 5, 13, 21")
+    assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -156,3 +156,19 @@ def test_generate_with_sampling_config(dtype):
         m.generate(**batch, generation_config=dict(do_sample=True, typical_p=0.5))
     with pytest.raises(ValueError):
         m.generate(**batch, generation_config=dict(do_sample=True, temperature=0.0))
+    # a batch whose prompt phase runs in several chunks draws what the un-chunked batch draws: the first tokens are counted by the
+    # GLOBAL batch row (gar_sample's row_offset, ABI 15 — ADVICE r5: rows i and b0 + i used to share their step-0 draw)
+    m1 = GARModel(cfg, synthetic_weights(cfg), dtype, prefill_chunk=1)
+    chunked = m1.generate(**batch, generation_config=gc, seed=777).sequences.cpu()
+    assert torch.equal(chunked, seq)
+    same = {k: (torch.cat([smp[0][k]] * 3, 0) if isinstance(smp[0][k], torch.Tensor) else [x for _ in range(3) for x in smp[0][k]])
+            for k in smp[0]}
+    rows = m1.generate(**same, generation_config=gc, seed=5).sequences.cpu()        # identical prompts: the rows must still differ
+    assert len({tuple(r.tolist()) for r in rows}) == 3
+    # options passed as keywords are laid over the config (HF generate semantics), never swallowed
+    assert torch.equal(m.generate(**batch, do_sample=True, temperature=0.8, top_k=min(50, V), top_p=0.9, max_new_tokens=NT,
+                                  seed=777).sequences.cpu(), seq)
+    with pytest.raises(hip.GarError, match="num_beams"):
+        m.generate(**batch, num_beams=4)
+    with pytest.raises(TypeError):
+        m.generate(**batch, not_an_option=1)
