@@ -912,62 +912,90 @@ def test_from_pretrained_hf_style_sharded_checkpoint(tiny, tmp_path, vision_bias
 
 # tolerances at full depth (23 ViT + 16 Llama layers): f32 rounding differences accumulate through 39 layers, stated
 # separately from the per-layer F32_LOGIT_TOL; measured values are printed by the test (pytest -s) and quoted in DESIGN.md
-FULL_DEPTH_F32_TOL = 2e-4     # measured 8.3e-6
-FULL_DEPTH_BF16_REL_L2 = 5.3e-2   # measured: first token 4.1e-2, worst of 64 steps 4.8e-2 (B = 64: 4.5e-2), top-1 agreement 0.906
-# floors = what was measured minus two points: a bf16 kernel regression worth 3-4 points must fail
-FULL_DEPTH_BF16_AGREE_B1 = 0.855       # B = 1: measured 0.875 (56 of 64 steps; round 5 build — 0.906 with round 3's kernels)
-FULL_DEPTH_BF16_AGREE = 0.92           # B = 64: measured 0.9404 over 64 x 64 steps
-FULL_DEPTH_BF16_AGREE_WORST_REGION = 0.80      # the MINIMUM of 64 per-region statistics of 64 steps each (sigma 0.03 per region): measured 0.859, 0.844 over this round's builds
+FULL_DEPTH_F32_TOL = 2e-4     # measured 7.8e-6 over 16 teacher-forced tokens
+FULL_DEPTH_BF16_REL_L2 = 5.3e-2   # measured: first token 3.2e-2 .. 3.9e-2, worst of 8 x 64 steps 4.4e-2 (B = 64: 4.5e-2; one region in round 5: 4.8e-2)
+# Top-1 agreement floors (DESIGN.md section 7 holds the table: statistic, n, measured value, sigma, floor, the commit that measured it).
+# A floor is the measured value minus THREE standard deviations of a binomial with the test's own n — wide enough that builds which
+# differ only in an fp32 rounding order pass, narrow enough that a kernel regression worth 5 points fails — and is FROZEN: a build
+# that falls below it has to be explained, the floor does not follow it.
+FULL_DEPTH_BF16_AGREE_B1 = 0.87        # B = 1, 8 regions x 64 steps (n = 512): measured 0.9082 (465 of 512), sigma 0.0128
+FULL_DEPTH_BF16_AGREE = 0.929          # B = 64, 64 regions x 64 steps (n = 4096): measured 0.9404 (rounds 4, 5 and 6 alike), sigma 0.0037
+FULL_DEPTH_BF16_AGREE_WORST_REGION = 0.80      # the MINIMUM of 64 per-region statistics of 64 steps each (sigma 0.03 per region): measured 0.859, 0.844
+FULL_DEPTH_ORACLE_TOKENS = 16          # tokens of the full-depth f32 run that meet the CPU oracle (rounds 3 - 5: 4)
+FULL_DEPTH_B1_REGIONS = 8
 
 
 def test_full_depth_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
-    """Full GAR-1B (23 + 16 layers, 17 tiles, S ~ 4.7k), the configuration bench.py times:
-    (1) f32 HIP vs the CPU oracle — the first 4 greedy tokens and their logits;
-    (2) bf16 HIP vs f32 HIP over a whole 64-token caption on IDENTICAL contexts (the bf16 model is fed the f32 model's
-        tokens): top-1 agreement rate, and every disagreement must sit at an f32 top-2 margin below twice the measured
-        bf16 logit error."""
+    """Full GAR-1B (23 + 16 layers, 17 tiles, S ~ 4.7k), the configuration bench.py times, one region per call (the reference's
+    calling pattern, demo/gar_with_mask.py:112-122):
+    (1) f32 HIP vs the CPU oracle over 16 tokens: the HIP run is fed the ORACLE's tokens, so every one of the 16 steps is compared on
+        the same context — logits within FULL_DEPTH_F32_TOL, the same token wherever the oracle's top-2 margin is not a near-tie —
+        and the free-running f32 caption starts with the oracle's tokens;
+    (2) bf16 HIP vs f32 HIP over whole 64-token captions of 8 DISTINCT regions on identical contexts (the bf16 model is fed the f32
+        model's tokens): n = 512 steps of top-1 agreement, and every disagreement must sit at an f32 top-2 margin below twice that
+        region's measured bf16 logit error."""
     from gar_amd import GARConfig
     from gar_amd.modeling_gar import GARModel
     from gar_amd.processing import GARProcessor
     from gar_amd.weights import synthetic_weights
+    from parity_util import F32_LOGIT_TOL as TOL, MARGIN_FACTOR, discrimination_stats
     cfg = GARConfig.gar_1b()
     W = synthetic_weights(cfg)
     proc = GARProcessor.from_config(cfg, max_num_tiles=16)
-    s = _sample(cfg, proc, 0, 1024, 1024)
+    R, NO = FULL_DEPTH_B1_REGIONS, FULL_DEPTH_ORACLE_TOKENS
+    ss = [_sample(cfg, proc, i, 1024, 1024) for i in range(R)]
+    s = ss[0]
     assert s["pixel_values"].shape[0] == 17
-    ref_seq, ref_logits = _oracle(W, cfg, s, 4, attn_impl="sdpa")
-    assert_discriminating(ref_seq, ref_logits)
+    ref_seq, ref_logits = _oracle(W, cfg, s, NO, attn_impl="sdpa")
+    assert_discriminating(ref_seq[:, :4], ref_logits[:, :4])
     m32 = GARModel(cfg, W, torch.float32)
-    o32 = m32.generate(**s, max_new_tokens=64, return_logits=True)
-    err = float((o32.logits[:, :4].cpu() - ref_logits).abs().max()) / float(ref_logits.abs().max())
-    print(f"full depth f32 HIP vs oracle: max|dlogit| / max|logit| = {err:.3e}")
-    assert o32.sequences[:, :4].cpu().tolist() == ref_seq.tolist()
+    tf = m32.generate(**s, max_new_tokens=NO, return_logits=True, forced_tokens=ref_seq)       # every step on the oracle's context
+    err = float((tf.logits.cpu() - ref_logits).abs().max()) / float(ref_logits.abs().max())
+    top2 = ref_logits.topk(2, -1).values[0]
+    clear = (top2[:, 0] - top2[:, 1]) >= MARGIN_FACTOR * TOL * float(ref_logits.abs().max())     # steps that are not near-ties
+    print(f"full depth f32 HIP vs oracle over {NO} teacher-forced tokens: max|dlogit| / max|logit| = {err:.3e}; "
+          f"{int(clear.sum())} of {NO} steps have a top-2 margin above {MARGIN_FACTOR} x the tolerance")
     assert err <= FULL_DEPTH_F32_TOL, err
-    seq32, lg32 = o32.sequences.clone(), o32.logits.cpu()
-    from parity_util import discrimination_stats
-    distinct, repeats, rel_margin = discrimination_stats(seq32[0].tolist(), lg32[0])
-    print(f"full depth f32 caption: {distinct} distinct of 64 tokens, {repeats} immediate repeats, min top-2 margin "
-          f"{rel_margin:.2e} x max|logit|")
-    assert repeats == 0 and distinct >= 52                   # no fixed point over the whole caption
+    assert int(clear.sum()) >= NO - 2
+    assert torch.equal(tf.sequences.cpu()[0][clear], ref_seq[0][clear])
+    seq32s, lg32s = [], []
+    for i, si in enumerate(ss):
+        o32 = m32.generate(**si, max_new_tokens=64, return_logits=True)
+        seq32s.append(o32.sequences.clone())
+        lg32s.append(o32.logits.cpu())
+        if i == 0:      # free-running: the oracle's tokens up to its first near-tie
+            k = NO if bool(clear.all()) else int((~clear).nonzero()[0])
+            assert o32.sequences[0, :k].cpu().tolist() == ref_seq[0, :k].tolist()
+            distinct, repeats, rel_margin = discrimination_stats(seq32s[0][0].tolist(), lg32s[0][0])
+            print(f"full depth f32 caption: {distinct} distinct of 64 tokens, {repeats} immediate repeats, min top-2 margin "
+                  f"{rel_margin:.2e} x max|logit|")
+            assert repeats == 0 and distinct >= 52                   # no fixed point over the whole caption
+    assert len({tuple(q[0].tolist()) for q in seq32s}) == R          # 8 different regions -> 8 different captions
     del m32
     torch.cuda.empty_cache()
-    sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in s.items()}
     m16 = GARModel(cfg, W, torch.bfloat16)
-    o16 = m16.generate(**sb, max_new_tokens=64, return_logits=True, forced_tokens=seq32)
-    lg16 = o16.logits.cpu()
-    rel = [_rel_l2(lg16[:, j], lg32[:, j]) for j in range(64)]
-    agree = (o16.sequences == seq32)[0].cpu()
-    rate = float(agree.float().mean())
-    max_err = float((lg16 - lg32).abs().max())
-    top2 = lg32.topk(2, -1).values[0]
-    margins = (top2[:, 0] - top2[:, 1])
-    print(f"full depth bf16 vs f32 (teacher forced, 64 tokens): top-1 agreement {rate:.3f}, first-token rel-L2 "
-          f"{rel[0]:.3e}, worst rel-L2 {max(rel):.3e}, max|dlogit| {max_err:.3e}, min f32 margin {float(margins.min()):.3e}")
-    assert max(rel) < FULL_DEPTH_BF16_REL_L2, max(rel)
-    for j in (~agree).nonzero().flatten().tolist():
-        assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
+    n_agree, worst_rel, first_rel = 0, 0.0, []
+    for i, si in enumerate(ss):
+        sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in si.items()}
+        o16 = m16.generate(**sb, max_new_tokens=64, return_logits=True, forced_tokens=seq32s[i])
+        lg16, lg32 = o16.logits.cpu(), lg32s[i]
+        rel = [_rel_l2(lg16[:, j], lg32[:, j]) for j in range(64)]
+        agree = (o16.sequences == seq32s[i])[0].cpu()
+        max_err = float((lg16 - lg32).abs().max())
+        t2 = lg32.topk(2, -1).values[0]
+        margins = t2[:, 0] - t2[:, 1]
+        for j in (~agree).nonzero().flatten().tolist():
+            assert float(margins[j]) < 2 * max_err, (i, j, float(margins[j]), max_err)
+        n_agree += int(agree.sum())
+        worst_rel = max(worst_rel, max(rel))
+        first_rel.append(rel[0])
+    rate = n_agree / (64.0 * R)
+    print(f"full depth bf16 vs f32 (teacher forced, {R} regions x 64 tokens, B = 1): top-1 agreement {rate:.4f} ({n_agree} of {64 * R}), "
+          f"first-token rel-L2 {min(first_rel):.3e} .. {max(first_rel):.3e}, worst rel-L2 {worst_rel:.3e}")
+    assert worst_rel < FULL_DEPTH_BF16_REL_L2, worst_rel
     assert rate >= FULL_DEPTH_BF16_AGREE_B1, rate          # a regression in a bf16 kernel must not hide below the measured value
     # free-running bf16 through the graph == the same model run eagerly (bit-identical kernels)
+    sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ss[0].items()}
     free_g = m16.generate(**sb, max_new_tokens=16)
     free_e = m16.generate(**sb, max_new_tokens=16, use_graph=False)
     assert torch.equal(free_g.sequences, free_e.sequences)
@@ -1064,25 +1092,24 @@ def test_config0_demo_asset_f32_parity(golden_dir, max_num_tiles, canvas):
 
 
 FULL_DEPTH_8B_F32_TOL = 2e-4
-# 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: bound 6e-2, measured 4.8e-2). Measured here: first token 7.1e-2 ... 7.2e-2,
-# worst of 32 steps 7.7e-2 ... 8.0e-2 across builds that differ only in an fp32 summation order (bias as the accumulator
-# start instead of an epilogue add): bound = the worst measured value + 10 %
+# 47 + 32 layers of bf16 rounding (GAR-1B's 23 + 16: bound 5.3e-2, measured 4.8e-2). Measured here: first token 7.1e-2 ... 7.2e-2,
+# worst step 7.7e-2 ... 8.0e-2 across builds that differ only in an fp32 summation order: bound = the worst measured value + 10 %
 FULL_DEPTH_8B_BF16_REL_L2 = 8.8e-2
-# 32 teacher-forced steps of ONE sequence: the statistic moves in steps of 1 / 32 and every build that changes an fp32 rounding
-# order anywhere in the 47 + 32 layers re-rolls the near-ties (f32 margin of the disagreeing steps: 1.7e-2 against a max |dlogit| of
-# 0.35). Measured over this project's builds: 0.875 (round 4), 0.969, 0.875 (dot2 row statistics / line-form GELU), 0.844 (fused RoPE
-# rotation in the ViT qkv epilogue) — a binomial with p ~ 0.89 and n = 32 has a standard deviation of 0.055. The floor is the mean of
-# the observations - 2 standard deviations; what a disagreeing step may look like is pinned separately just below (its f32 margin
-# < 2 x the largest logit error), and the B = 64 GAR-1B test above holds the tight floor on 4096 steps.
-FULL_DEPTH_8B_BF16_AGREE = 0.78
+# 16 DISTINCT regions x 32 teacher-forced steps in one batch (n = 512; rounds 3 - 5 ran 32 steps of ONE sequence, sigma 0.055, and the
+# floor followed the builds down to 0.78). Measured 0.8359 (428 of 512; sigma 0.0164; the worst of the 16 regions 0.688 = 22 of 32): the
+# population value sits BELOW what the single sequence of rounds 3 - 5 happened to show (0.844 ... 0.969) — 79 layers of bf16 rounding
+# (rel-L2 of the logits 5.3e-2 ... 7.7e-2) against the synthetic model's top-2 margins. Floor = measured - 3 sigma, frozen (DESIGN.md
+# section 7); what a disagreeing step may look like is pinned separately (its f32 margin < 2 x its region's largest logit error).
+FULL_DEPTH_8B_REGIONS = 16
+FULL_DEPTH_8B_BF16_AGREE = 0.787
 
 
 def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     """Full GAR-8B (BASELINE.json configs[3]: 47 PE-G/14 layers with head_dim 96 and no cls token + 32 Llama-3.1-8B layers
     with head_dim 128 and an untied head; max_num_tiles=8 -> 5 tiles, S ~ 1.6k):
     (1) f32 HIP vs the CPU oracle — the first 2 greedy tokens (prefill + one decode step) and their logits;
-    (2) bf16 HIP vs f32 HIP teacher-forced over 32 tokens: per-step relative L2 of the logits, top-1 agreement, every
-        disagreement at an f32 margin inside the measured bf16 logit error."""
+    (2) bf16 HIP vs f32 HIP teacher-forced over 32 tokens of 16 DISTINCT regions in one batch (n = 512 steps): per-step relative L2
+        of the logits, top-1 agreement, every disagreement at an f32 margin inside that region's measured bf16 logit error."""
     from gar_amd import GARConfig
     from gar_amd.modeling_gar import GARModel
     from gar_amd.processing import GARProcessor
@@ -1090,40 +1117,51 @@ def test_full_depth_gar8b_f32_vs_oracle_and_bf16_vs_f32_teacher_forced():
     cfg = GARConfig.gar_8b()
     W = synthetic_weights(cfg)
     proc = GARProcessor.from_config(cfg, max_num_tiles=8)
-    s = _sample(cfg, proc, 0, 1024, 1024)
+    R = FULL_DEPTH_8B_REGIONS
+    ss = [_sample(cfg, proc, i, 1024, 1024) for i in range(R)]
+    s = ss[0]
     assert s["pixel_values"].shape[0] == 5
     ref_seq, ref_logits = _oracle(W, cfg, s, 2, attn_impl="sdpa")
     NT = 32
     m32 = GARModel(cfg, W, torch.float32)
-    o32 = m32.generate(**s, max_new_tokens=NT, return_logits=True)
-    err = float((o32.logits[:, :2].cpu() - ref_logits).abs().max()) / float(ref_logits.abs().max())
+    o1 = m32.generate(**s, max_new_tokens=2, return_logits=True)
+    err = float((o1.logits.cpu() - ref_logits).abs().max()) / float(ref_logits.abs().max())
     print(f"GAR-8B full depth f32 HIP vs oracle: max|dlogit| / max|logit| = {err:.3e}")
-    assert o32.sequences[:, :2].cpu().tolist() == ref_seq.tolist()
+    assert o1.sequences.cpu().tolist() == ref_seq.tolist()
     assert err <= FULL_DEPTH_8B_F32_TOL, err
-    seq32, lg32 = o32.sequences.clone(), o32.logits.cpu()
+    batch = dict(input_ids=torch.cat([x["input_ids"] for x in ss]), pixel_values=torch.cat([x["pixel_values"] for x in ss]),
+                 global_mask_values=torch.cat([x["global_mask_values"] for x in ss]), bboxes=[x["bboxes"][0] for x in ss],
+                 aspect_ratios=torch.cat([x["aspect_ratios"] for x in ss]))
+    o32 = m32.generate(**batch, max_new_tokens=NT, return_logits=True)
+    seq32, lg32 = o32.sequences.clone(), o32.logits.cpu()                 # [R, NT], [R, NT, V]
+    assert seq32[0, :2].cpu().tolist() == ref_seq[0].tolist()             # the batched row 0 = the single run = the oracle
+    assert len({tuple(r) for r in seq32.cpu().tolist()}) == R
     from parity_util import discrimination_stats
     distinct, repeats, rel_margin = discrimination_stats(seq32[0].tolist(), lg32[0])
     print(f"GAR-8B full depth f32 caption: {distinct} distinct of {NT} tokens, {repeats} immediate repeats, min top-2 "
           f"margin {rel_margin:.2e} x max|logit|")
-    del m32, o32
+    del m32, o32, o1
     torch.cuda.empty_cache()
-    sb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in s.items()}
+    bb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
     m16 = GARModel(cfg, W, torch.bfloat16)
     del W
-    o16 = m16.generate(**sb, max_new_tokens=NT, return_logits=True, forced_tokens=seq32)
+    o16 = m16.generate(**bb, max_new_tokens=NT, return_logits=True, forced_tokens=seq32)
     lg16 = o16.logits.cpu()
-    rel = [_rel_l2(lg16[:, j], lg32[:, j]) for j in range(NT)]
-    agree = (o16.sequences == seq32)[0].cpu()
+    rel = ((lg16 - lg32).double().norm(dim=-1) / lg32.double().norm(dim=-1))         # [R, NT]
+    agree = (o16.sequences == seq32).cpu()
     rate = float(agree.float().mean())
-    max_err = float((lg16 - lg32).abs().max())
-    top2 = lg32.topk(2, -1).values[0]
-    margins = (top2[:, 0] - top2[:, 1])
-    print(f"GAR-8B full depth bf16 vs f32 (teacher forced, {NT} tokens): top-1 agreement {rate:.3f}, first-token rel-L2 "
-          f"{rel[0]:.3e}, worst rel-L2 {max(rel):.3e}, max|dlogit| {max_err:.3e}, min f32 margin {float(margins.min()):.3e}")
-    assert max(rel) < FULL_DEPTH_8B_BF16_REL_L2, max(rel)
-    for j in (~agree).nonzero().flatten().tolist():
-        assert float(margins[j]) < 2 * max_err, (j, float(margins[j]), max_err)
+    err_row = (lg16 - lg32).abs().amax(dim=(1, 2))                                   # [R]
+    top2 = lg32.topk(2, -1).values
+    margins = top2[..., 0] - top2[..., 1]
+    print(f"GAR-8B full depth bf16 vs f32 (teacher forced, {R} regions x {NT} tokens): top-1 agreement {rate:.4f} ({int(agree.sum())} of "
+          f"{R * NT}; worst region {float(agree.float().mean(1).min()):.3f}), first-token rel-L2 {float(rel[:, 0].min()):.3e} .. "
+          f"{float(rel[:, 0].max()):.3e}, worst rel-L2 {float(rel.max()):.3e}, max|dlogit| {float(err_row.max()):.3e}")
+    assert float(rel.max()) < FULL_DEPTH_8B_BF16_REL_L2, float(rel.max())
+    bad = (~agree) & (margins >= 2 * err_row[:, None])
+    assert not bool(bad.any()), bad.nonzero().tolist()[:8]
     assert rate >= FULL_DEPTH_8B_BF16_AGREE, rate          # a regression in the head_dim 96 / 128 kernels must not hide below it
+    sb = {k: (v[:1] if torch.is_tensor(v) and k != "pixel_values" and k != "global_mask_values" else v) for k, v in bb.items()}
+    sb["pixel_values"], sb["global_mask_values"], sb["bboxes"] = bb["pixel_values"][:5], bb["global_mask_values"][:5], bb["bboxes"][:1]
     free_g = m16.generate(**sb, max_new_tokens=8)
     free_e = m16.generate(**sb, max_new_tokens=8, use_graph=False)
     assert torch.equal(free_g.sequences, free_e.sequences)
