@@ -57,6 +57,23 @@ def test_library_links_no_vendor_math_library():
             assert call not in src, (f, call)
 
 
+def test_library_has_no_environment_switches_and_no_process_global_knobs():
+    """no global state besides the last-error string — the libraries read no environment variable (getenv is not
+    among their undefined symbols; round 5 read three) and export no switch (every exported gar_* symbol is an entry point of
+    include/gar_hip.h)."""
+    header = open(os.path.join(ROOT, "include", "gar_hip.h")).read()
+    declared = set(re.findall(r"\b(gar_[a-z0-9_]+)\s*\(", header))
+    for name in ("libgar_hip.so", "libgar_hip_f16.so"):
+        so = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd", name)
+        out = subprocess.run(["nm", "-D", so], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        undefined = {ln.split()[-1].split("@")[0] for ln in out.stdout.splitlines() if " U " in ln}
+        assert not ({"getenv", "secure_getenv", "setenv", "putenv"} & undefined), undefined & {"getenv", "secure_getenv"}
+        exported = {ln.split()[-1] for ln in out.stdout.splitlines() if " T " in ln and ln.split()[-1].startswith("gar_")}
+        assert exported <= declared, sorted(exported - declared)
+        assert not any("enable" in e or "switch" in e for e in exported), exported
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "grasp-any-region_amd", "gar_amd")
     for f in os.listdir(pkg):

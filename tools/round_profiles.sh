@@ -3,7 +3,7 @@
 # SQ/GRBM counter passes of the GEMM and attention micro-benchmarks, a clock/power trace, and the default bench line.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-R=${R:-r5}
+R=${R:-r6}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof
 mkdir -p $O
 python bench.py --steps 3 --warmup 1 > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
