@@ -861,8 +861,7 @@ class GARModel:
             # (ADVICE r1 #5 / r2): what the kernels do with such inputs (clamped slots / ids, P*P rows written from the span
             # head) is defined but not what the reference computes. The per-sample "has a bbox for crop token c" bits are the
             # only host data (B int32, one small pinned upload).
-            hb = torch.tensor([sum(1 << ci for ci, t in enumerate(crop_ids) if str(t) in bboxes[b]) for b in range(B)],
-                              dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            hb = self._upload([sum(1 << ci for ci, t in enumerate(crop_ids) if str(t) in bboxes[b]) for b in range(B)], torch.int32)
             if getattr(self, "_input_flags", None) is None:
                 self._input_flags = torch.zeros(1, dtype=torch.int32, device=self.device)
             ops.input_check(ids, self.E.shape[0], counts, n_rows, spans, P * P, hb, self._input_flags)
@@ -1067,6 +1066,21 @@ class GARModel:
     def _qkv_buf(self, key, B, S, Hq, Hkv, hd):
         """the [B*S, (Hq + 2 Hkv) hd] qkv GEMM output of the unfused prefill path (f32 / FOLD_NORMS off): lazily allocated"""
         return self._buf(key, "qkv", (B * S, (Hq + 2 * Hkv) * hd))
+
+    def _upload(self, values, dtype, cache: bool = True) -> torch.Tensor:
+        """small host constants of a request (eos ids, has-bbox bits, sampling parameters) as a device tensor. The values repeat from
+        call to call (one eos set, one crop-token pattern per evaluation loop): their device copies are cached by value — no pinned
+        host allocation and no upload per generate() (visible at batch 1). A cache miss is one pageable H2D copy."""
+        key = (dtype, tuple(values))
+        memo = self.__dict__.setdefault("_upload_cache", {})
+        t = memo.get(key) if cache else None
+        if t is None:
+            t = torch.tensor(list(values), dtype=dtype).to(self.device)
+            if cache:
+                if len(memo) > 256:
+                    memo.clear()
+                memo[key] = t
+        return t
 
     def _head(self, last_rows: torch.Tensor, B: int, out_tokens, st, cur=None, normed: Optional[torch.Tensor] = None,
               finished=None, row0: int = 0):
@@ -1311,7 +1325,7 @@ class GARModel:
         st["done_count"].zero_()
         st["eos_ids"].fill_(-1)
         if eos_list and eos_on_device:
-            st["eos_ids"][:len(eos_list)].copy_(torch.tensor(eos_list, dtype=torch.int64).pin_memory(), non_blocking=True)
+            st["eos_ids"][:len(eos_list)].copy_(self._upload(eos_list, torch.int64))
         st["sampling"] = sampling is not None
         if sampling is not None:
             if seed is None:          # HF draws from torch's global generator: so does the key of this request (torch.manual_seed reproduces it)
@@ -1319,8 +1333,8 @@ class GARModel:
                 if torch.distributed.is_available() and torch.distributed.is_initialized():
                     # identically seeded data-parallel ranks must not replay one stream on different regions
                     seed = (seed ^ (0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1))) & (2 ** 62 - 1)
-            st["sample_params"].copy_(torch.tensor([sampling[0], sampling[1], float(sampling[2]), 0.0]).pin_memory(), non_blocking=True)
-            st["sample_seed"].copy_(torch.tensor([int(seed)], dtype=torch.int64).pin_memory(), non_blocking=True)
+            st["sample_params"].copy_(self._upload([sampling[0], sampling[1], float(sampling[2]), 0.0], torch.float32))
+            st["sample_seed"].copy_(self._upload([int(seed)], torch.int64, cache=False))
         V = cfg.mllm_config.text_config.vocab_size
         tiles = 0
         if pixel_values is not None:

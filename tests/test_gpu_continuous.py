@@ -180,3 +180,32 @@ def test_continuous_at_gar1b_dimensions_f32():
     for t, e in zip(tickets, exp):
         assert res[t] == e, (t, res[t], e)
     assert cb.stats["prompt_passes"] >= 3 and cb.stats["decode_steps"] < sum(max(lens[i:i + B]) - 1 for i in range(0, 10, B)) + NT
+
+
+def test_two_batchers_on_one_model_do_not_share_state(tiny):
+    """every ContinuousBatcher owns its KV-state slots of the model — two batchers with the same (slots, Smax), pumped
+    alternately, give each region the tokens of its single-region run (they used to alias one cache, token log and graph)."""
+    from gar_amd.continuous import ContinuousBatcher
+    from gar_amd.modeling_gar import GARModel
+    cfg, W, proc = tiny
+    B, NT = 4, 12
+    m = GARModel(cfg, W, torch.float32)
+    sa = [_sample(cfg, proc, 300 + i) for i in range(2 * B)]
+    sb = [_sample(cfg, proc, 400 + i) for i in range(2 * B)]
+    streams = [m.generate(**s, max_new_tokens=NT).sequences[0].cpu().tolist() for s in sa + sb]
+    eos, lens = _pick_eos(streams, 4, NT)
+    exp = _single_runs(m, sa + sb, NT, eos)
+    a = ContinuousBatcher(m, slots=B, max_new_tokens=NT, eos_token_id=eos, poll_every=1, admit_min=1)
+    b = ContinuousBatcher(m, slots=B, max_new_tokens=NT, eos_token_id=eos, poll_every=1, admit_min=1)
+    assert {a.DEC_SLOT, a.STAGE_SLOT}.isdisjoint({b.DEC_SLOT, b.STAGE_SLOT}) and min(a.DEC_SLOT, b.DEC_SLOT) >= 2
+    ta = [a.submit(s) for s in sa]
+    tb = [b.submit(s) for s in sb]
+    for _ in range(400):                       # alternate single cycles of the two loops
+        if a.queue or a.n_active:
+            a._cycle(True)
+        if b.queue or b.n_active:
+            b._cycle(True)
+        if not (a.queue or a.n_active or b.queue or b.n_active):
+            break
+    assert [a.results[t] for t in ta] == exp[:2 * B]
+    assert [b.results[t] for t in tb] == exp[2 * B:]
