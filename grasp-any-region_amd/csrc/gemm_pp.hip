@@ -265,11 +265,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
 #define READ_B(st, kk)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
         bq[j] = *reinterpret_cast<const bf16x8*>(smem + ((st) ^ ((kk) ? 64 : 0)) + (j >> 1) * BJ1 + (j & 1) * BJ0);
+// Issue order of a phase's 16 MFMAs (4 m-tiles x 4 n-tiles, independent accumulators): n-tile outer, m-tiles in SNAKE order, so
+// that consecutive MFMAs always share one operand fragment — the W fragment for four in a row, the A fragment across the turn.
+// The chip is power-limited in this loop (profiles/r6_gemm_lone_wave.txt), and an operand that does not change between two MFMAs
+// does not toggle its lanes: +0.9 % weighted over the planner's shapes against the row-major order (every fourth MFMA changed BOTH
+// operands), same box, 4 x 8 repetitions alternated (profiles/r6_gemm_mfma_order.txt); outputs bit-identical (order of issue only).
+#ifndef PP_MMA_ORDER      /* diagnostic builds: 0 = m-tile outer, n-tiles 0..3 (rounds 2 - 5), 1 = that in snake order, 2 = n-tile outer, 3 = n-tile outer, snake */
+#define PP_MMA_ORDER 3
+#endif
 #define MMA(mh)                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+    if (PP_MMA_ORDER >= 2) {                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-            acc[(mh) * 4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[(mh) * 4 + i][j]); \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                            \
+                const int i = (PP_MMA_ORDER == 3 && (j & 1)) ? 3 - ii : ii;                              \
+                acc[(mh) * 4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[(mh) * 4 + i][j]);                \
+            }                                                                                            \
+    } else {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
+                const int j = (PP_MMA_ORDER == 1 && (i & 1)) ? 3 - jj : jj;                              \
+                acc[(mh) * 4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[(mh) * 4 + i][j]);                \
+            }                                                                                            \
+    }                                                                                                    \
     __builtin_amdgcn_s_setprio(0);
 #ifdef PP_TIMELINE   /* diagnostic build (tools/gemm_timeline.py): shader-clock stamps around every barrier */
 #if PP_TIMELINE >= 2   /* light: only the stamps around phase 0 (barriers 7 -> 0), so the other phases run undisturbed */
@@ -676,9 +694,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const gar_gemm_par
             bW = (unsigned)pn_ * rbW + (unsigned)(pt_ * PBK * 2);                                                    \
             if (GATHER) rsAc = pt_ >= GATHER_KT_PER_TENSOR ? rsA2 : rsA;                                             \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        if (PP_MMA_ORDER >= 2) {                                                                                     \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
-                acc[4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[4 + i][j]);        \
+                _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                    \
+                    const int i = (PP_MMA_ORDER == 3 && (j & 1)) ? 3 - ii : ii;                                      \
+                    acc[4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[4 + i][j]);                                      \
+                }                                                                                                    \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                    \
+                    const int j = (PP_MMA_ORDER == 1 && (i & 1)) ? 3 - jj : jj;                                      \
+                    acc[4 + i][j] = MFMA_16x16x32(bq[j], af[i], acc[4 + i][j]);                                      \
+                }                                                                                                    \
+        }                                                                                                            \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
             __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                                                       \
